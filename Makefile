@@ -1,0 +1,59 @@
+# Top-level build: everything is compiled for gfx950 (MI355X) only.
+#
+#   make            -> lib + cli + oracle
+#   make lib        -> openmp-parallel-computing_amd/lib/libgrayhip.so   (HIP kernels + C ABI)
+#   make cli        -> bin/grayscale, bin/grayscale_sobel                (drop-in CLIs, same argv/stdout/exit codes
+#                                                                         as the reference's monolithic/bin/grayscale)
+#   make oracle     -> oracle/liboracle.so (+ oracle/_ref/ when /root/reference is present) -- test infrastructure
+#
+# hipcc cross-compiles gfx950 without a GPU present.
+
+PKG      := openmp-parallel-computing_amd
+CSRC     := $(PKG)/csrc
+LIBDIR   := $(PKG)/lib
+LIB      := $(LIBDIR)/libgrayhip.so
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+
+# -ffp-contract=off: the IEEE luma model needs un-fused mul/add (FMA mode calls fmaf explicitly).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
+            -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/shim.hip
+HIP_OBJS := $(HIP_SRCS:.hip=.o)
+HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h
+
+CXX      ?= g++
+CXXFLAGS := -O2 -std=c++17 -Wall -Iinclude -I$(CSRC)
+
+all: lib cli oracle
+
+lib: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+
+CLI_COMMON := $(CSRC)/cli/image_io.cpp $(CSRC)/cli/jpeg_decode.cpp
+cli: bin/grayscale bin/grayscale_sobel
+
+bin/grayscale: $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h $(LIB)
+	@mkdir -p bin
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
+	    -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+bin/grayscale_sobel: $(CSRC)/cli/main_sobel.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h $(LIB)
+	@mkdir -p bin
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_sobel.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
+	    -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(HIP_OBJS) $(LIB) bin/grayscale bin/grayscale_sobel
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib cli oracle clean

@@ -1,0 +1,140 @@
+/*
+ * grayhip.h -- C ABI of libgrayhip.so: the MI355X (gfx950) implementation of the reference's
+ * per-pixel hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * PedemonteGiacomo/OpenMp-Parallel-Computing):
+ *
+ *   convert_to_grayscale / gh_gray_*      monolithic/include/parallel_to_grayscale.h:4,
+ *                                         monolithic/src/parallel_to_grayscale.c:5-17
+ *   sobel_edge / gh_sobel_*               monolithic/include/sobel.h:3-5, monolithic/src/sobel.c:6-25
+ *   gh_extract_plane_dev                  monolithic/src/main_with_sobel.c:57-59
+ *   gh_replicate_plane_dev                monolithic/src/main_with_sobel.c:65-73
+ *   gh_pipeline_*                         monolithic/src/main_with_sobel.c:49-76, monolithic/src/main.c:30-38
+ *   gh_conv3x3_rgb8_dev                   old/parallel_convolution.c:8-24   (u8 frames, zero border)
+ *   gh_sum_rgb8_dev                       old/parallel_avg_pixel.c:5-42     (exact u64 channel sums)
+ *   gh_mean_gray_minmax_dev               old/parallel_to_grayscale.c:7-38  (u8 frames)
+ *
+ * Conventions
+ *   - *_dev functions take DEVICE pointers, enqueue work on `stream` (a hipStream_t passed as
+ *     void*, NULL = the default stream) and return without synchronising.
+ *   - *_host functions and the two reference-named symbols take HOST pointers, are synchronous
+ *     and own their staging buffers (caller-owned image buffers, exactly like the reference).
+ *   - Return value: 0 on success, a negative gh_status otherwise; gh_last_error() returns the
+ *     message of the calling thread's last failure.  There is NO CPU fallback anywhere: if HIP
+ *     or the GPU is unavailable the call fails.
+ *   - `mode`: GH_MODE_IEEE reproduces the reference built with `-O3 -fopenmp` (this is the build that
+ *     produced the reference's golden images/test_gray.png); GH_MODE_FMA reproduces the
+ *     `-O3 -march=native -ffast-math` build on an FMA x86 host (monolithic/Makefile:2).
+ *   - Sobel border: the reference never writes dst's border; the *_dev kernels write 0 there
+ *     (what the reference CLI shows in practice), the host shim `sobel_edge` leaves it untouched.
+ */
+#ifndef GRAYHIP_H
+#define GRAYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GH_API __attribute__((visibility("default")))
+
+typedef void *gh_stream_t;   /* hipStream_t */
+
+enum gh_mode { GH_MODE_IEEE = 0, GH_MODE_FMA = 1 };
+
+enum gh_status {
+    GH_OK = 0,
+    GH_ERR_HIP = -1,        /* a HIP runtime call failed (message has the hipError string) */
+    GH_ERR_ARG = -2,        /* bad argument (NULL pointer, channels outside 1..4, src==dst, ...) */
+    GH_ERR_NO_DEVICE = -3   /* no usable gfx950 device */
+};
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+GH_API int gh_init(int device);                 /* select device, warm the context; idempotent */
+GH_API int gh_device_count(void);
+GH_API const char *gh_last_error(void);
+GH_API const char *gh_version(void);
+GH_API int gh_default_mode(void);               /* GRAYHIP_MODE=ieee|fma, default ieee */
+
+GH_API int gh_malloc(void **dptr, size_t nbytes);
+GH_API int gh_free(void *dptr);
+GH_API int gh_memset_dev(void *dptr, int value, size_t nbytes, gh_stream_t stream);
+GH_API int gh_copy_h2d(void *dst_dev, const void *src_host, size_t nbytes, gh_stream_t stream);
+GH_API int gh_copy_d2h(void *dst_host, const void *src_dev, size_t nbytes, gh_stream_t stream);
+GH_API int gh_stream_sync(gh_stream_t stream);
+
+/* ---- device-resident kernels (the measured hot path) ------------------------------------- */
+
+/* RGB8/RGBA8 interleaved -> 1 B/px luma plane.  3 R + 1 W bytes per pixel (channels==3).
+ * channels 1 or 2: plane = channel 0 (grey / grey+alpha input). */
+GH_API int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, int channels,
+                                     int mode, gh_stream_t stream);
+
+/* Reference ABI semantics on device memory: R=G=B=luma in place, alpha untouched.
+ * channels<3 is a no-op (the reference reads out of bounds there). */
+GH_API int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mode, gh_stream_t stream);
+
+/* 3x3 Sobel magnitude, u8 plane -> u8 plane, whole frame; border pixels are written as 0.
+ * width<3 or height<3: dst is all zeros. */
+GH_API int gh_sobel_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, gh_stream_t stream);
+
+/* Row band of a frame (row sharding): computes `rows` output rows.  src/dst point at the band's
+ * first row.  If !top_is_border the row above the band (src - width) must be readable (halo
+ * row); likewise below.  A band edge that IS the frame border is written as 0. */
+GH_API int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows,
+                                int top_is_border, int bottom_is_border, gh_stream_t stream);
+
+/* Fused RGB -> luma -> Sobel; the luma plane never touches HBM.  Same band semantics as above
+ * (halo rows are RGB rows).  3 R + 1 W bytes per pixel. */
+GH_API int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels,
+                                        int mode, int top_is_border, int bottom_is_border, gh_stream_t stream);
+
+GH_API int gh_extract_plane_dev(const uint8_t *img, uint8_t *plane, size_t npix, int channels, gh_stream_t stream);
+GH_API int gh_replicate_plane_dev(const uint8_t *plane, uint8_t *img, size_t npix, int channels, gh_stream_t stream);
+
+/* luma of an already grey plane: v -> lum(v,v,v) (what pass k+1 of the reference CLIs does
+ * to pass k's output; not the identity for 13 grey levels in IEEE mode). */
+GH_API int gh_gray_of_plane_dev(const uint8_t *src, uint8_t *dst, size_t npix, int mode, gh_stream_t stream);
+
+/* generic 3x3 integer convolution on interleaved RGB8, zero border, out = clamp(trunc(sum/norm)) */
+GH_API int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height,
+                               const int32_t kernel[9], int32_t norm, gh_stream_t stream);
+
+/* exact per-channel sums of an RGB8 frame, ADDED into sums_dev[0..2] (device u64[3], zero it first) */
+GH_API int gh_sum_rgb8_dev(const uint8_t *rgb, size_t npix, uint64_t *sums_dev, gh_stream_t stream);
+
+/* g=(r+g+b)/3 replicated to 3 channels; minmax_dev[0]=min, [1]=max must be pre-set to 256 / -1 */
+GH_API int gh_mean_gray_minmax_dev(const uint8_t *rgb, uint8_t *out_rgb, size_t npix, int32_t *minmax_dev,
+                                   gh_stream_t stream);
+
+/* `passes` x (gray -> sobel -> replicate) on a device-resident interleaved image, reference
+ * semantics (main_with_sobel.c:51-74).  gray_ws / edge_ws: width*height bytes of scratch each. */
+GH_API int gh_pipeline_gray_sobel_dev(uint8_t *img, int width, int height, int channels, int passes, int mode,
+                                      uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream);
+
+/* ---- host-pointer entry points (drop-in boundary) ---------------------------------------- */
+GH_API int gh_convert_to_grayscale_host(unsigned char *data, int width, int height, int channels, int mode);
+GH_API int gh_gray_passes_host(unsigned char *data, int width, int height, int channels, int passes, int mode,
+                               double *kernel_seconds);
+GH_API int gh_sobel_edge_host(const unsigned char *src, unsigned char *dst, int width, int height);
+GH_API int gh_pipeline_gray_sobel_host(unsigned char *img, int width, int height, int channels, int passes,
+                                       int mode, double *kernel_seconds);
+GH_API int gh_sum_rgb8_host(const unsigned char *rgb, size_t npix, uint64_t sums[3]);
+
+/* The reference's own symbols (same prototypes as monolithic/include/ headers).  They return void in
+ * the reference, so a failure is reported on stderr and the process is aborted -- never a
+ * silent CPU fallback.  mode = gh_default_mode(). */
+GH_API void convert_to_grayscale(unsigned char *data, int width, int height, int channels);
+GH_API void sobel_edge(const unsigned char *src, unsigned char *dst, int width, int height);
+
+/* ---- self tests that need the device (used by tests/ through the C ABI) ------------------- */
+/* counts m in [0, m_max] for which the device's sqrt mapping differs from min(255, isqrt(m)) */
+GH_API int gh_selftest_sobel_sqrt(uint32_t m_max, uint64_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

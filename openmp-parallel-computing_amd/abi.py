@@ -1,0 +1,85 @@
+"""ctypes view of libgrayhip.so -- the C ABI declared in include/grayhip.h.
+
+This is the only way Python reaches the hot path: every call lands in the hand-written gfx950
+kernels.  There is no Python/NumPy/torch fallback; if the library is missing or a call fails a
+GrayHipError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libgrayhip.so")
+REPO_ROOT = os.path.dirname(_PKG_DIR)
+
+MODE_IEEE = 0
+MODE_FMA = 1
+
+_u8p = C.c_void_p      # device or host byte pointer, passed as an integer address
+_stream = C.c_void_p
+
+# name -> (restype, argtypes); kept in step with include/grayhip.h (tests/test_abi_symbols.py checks)
+SIGNATURES = {
+    "gh_init": (C.c_int, [C.c_int]),
+    "gh_device_count": (C.c_int, []),
+    "gh_last_error": (C.c_char_p, []),
+    "gh_version": (C.c_char_p, []),
+    "gh_default_mode": (C.c_int, []),
+    "gh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "gh_free": (C.c_int, [C.c_void_p]),
+    "gh_memset_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _stream]),
+    "gh_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
+    "gh_copy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
+    "gh_stream_sync": (C.c_int, [_stream]),
+    "gh_gray_rgb8_to_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
+    "gh_gray_inplace_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
+    "gh_sobel_u8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _stream]),
+    "gh_sobel_u8_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_gray_sobel_fused_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_extract_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
+    "gh_replicate_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
+    "gh_gray_of_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
+    "gh_conv3x3_rgb8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int32, _stream]),
+    "gh_sum_rgb8_dev": (C.c_int, [_u8p, C.c_size_t, C.c_void_p, _stream]),
+    "gh_mean_gray_minmax_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_void_p, _stream]),
+    "gh_pipeline_gray_sobel_dev": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _stream]),
+    "gh_convert_to_grayscale_host": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gh_gray_passes_host": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gh_sobel_edge_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int]),
+    "gh_pipeline_gray_sobel_host": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gh_sum_rgb8_host": (C.c_int, [_u8p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "convert_to_grayscale": (None, [_u8p, C.c_int, C.c_int, C.c_int]),
+    "sobel_edge": (None, [_u8p, _u8p, C.c_int, C.c_int]),
+    "gh_selftest_sobel_sqrt": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64)]),
+}
+
+
+class GrayHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libgrayhip.so (no GPU work happens here) and type every exported symbol."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GrayHipError(
+                f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
+                "there is no CPU fallback for the hot path")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gh_last_error().decode(errors="replace")
+        raise GrayHipError(f"{what or 'libgrayhip call'} failed (status {rc}): {msg}")

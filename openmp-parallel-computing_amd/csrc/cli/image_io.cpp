@@ -1,0 +1,313 @@
+// image_io.cpp -- PNG (decode + encode, on zlib) and binary PNM decode for the drop-in CLIs.
+// JPEG decode lives in jpeg_decode.cpp.  See image_io.h for the contract this mirrors
+// (the reference's stbi_load(..., 0) / stbi_write_png calls in monolithic/src/main.c:21,41).
+#include "image_io.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+bool gh_jpeg_decode(const uint8_t *data, size_t size, GhImage &out, std::string &err);   // jpeg_decode.cpp
+
+namespace {
+
+inline uint32_t be32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+inline int paeth(int a, int b, int c)
+{
+    const int p = a + b - c;
+    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    if (pb <= pc) return b;
+    return c;
+}
+
+// ---- PNG decode ---------------------------------------------------------------------------------
+
+struct PngHeader {
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    int file_channels() const { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4; }
+};
+
+// undo the scanline filters of one (sub-)image in place; `raw` holds h rows of (1 + rowbytes)
+bool unfilter(uint8_t *raw, size_t rowbytes, uint32_t h, int bpp, std::string &err)
+{
+    std::vector<uint8_t> zero(rowbytes, 0);
+    const uint8_t *prev = zero.data();
+    for (uint32_t y = 0; y < h; ++y) {
+        uint8_t *line = raw + (size_t)y * (rowbytes + 1);
+        const int ft = line[0];
+        uint8_t *cur = line + 1;
+        switch (ft) {
+        case 0: break;
+        case 1: for (size_t i = bpp; i < rowbytes; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+        case 2: for (size_t i = 0; i < rowbytes; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]); break;
+        case 3:
+            for (size_t i = 0; i < rowbytes; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0;
+                cur[i] = (uint8_t)(cur[i] + ((a + prev[i]) >> 1));
+            }
+            break;
+        case 4:
+            for (size_t i = 0; i < rowbytes; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0;
+                const int c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+                cur[i] = (uint8_t)(cur[i] + paeth(a, prev[i], c));
+            }
+            break;
+        default: err = "bad PNG filter type"; return false;
+        }
+        prev = cur;
+    }
+    return true;
+}
+
+// sample s (0-based, in units of `depth` bits) of an unfiltered row -> 16-bit-wide raw value
+inline uint32_t sample_at(const uint8_t *row, size_t s, int depth)
+{
+    if (depth == 8) return row[s];
+    if (depth == 16) return (uint32_t)row[2 * s] << 8 | row[2 * s + 1];
+    const size_t bit = s * depth;
+    return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
+}
+
+bool decode_png(const uint8_t *data, size_t size, GhImage &out, std::string &err)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 || memcmp(data, sig, 8) != 0) { err = "not a PNG"; return false; }
+    PngHeader hd;
+    std::vector<uint8_t> idat, plte, trns;
+    bool have_ihdr = false, have_trns = false;
+    size_t pos = 8;
+    while (pos + 8 <= size) {
+        const uint32_t len = be32(data + pos);
+        const uint8_t *type = data + pos + 4;
+        const uint8_t *body = data + pos + 8;
+        if ((size_t)len > size - pos - 8) { err = "truncated PNG chunk"; return false; }
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13) { err = "bad IHDR"; return false; }
+            hd.w = be32(body); hd.h = be32(body + 4);
+            hd.depth = body[8]; hd.ctype = body[9]; hd.interlace = body[12];
+            if (body[10] != 0 || body[11] != 0 || hd.interlace > 1) { err = "unsupported PNG method"; return false; }
+            have_ihdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!memcmp(type, "tRNS", 4)) {
+            trns.assign(body, body + len);
+            have_trns = true;
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (!have_ihdr || hd.w == 0 || hd.h == 0) { err = "PNG without a valid IHDR"; return false; }
+    const bool depth_ok = (hd.ctype == 0 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8 || hd.depth == 16)) ||
+                          (hd.ctype == 3 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8)) ||
+                          ((hd.ctype == 2 || hd.ctype == 4 || hd.ctype == 6) && (hd.depth == 8 || hd.depth == 16));
+    if (!depth_ok) { err = "bad PNG colour type / bit depth"; return false; }
+    if (hd.ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
+    if ((uint64_t)hd.w * hd.h > (1ull << 31)) { err = "PNG too large"; return false; }
+
+    const int fch = hd.file_channels();
+    const int bits_pp = fch * hd.depth;
+    const int bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+
+    // pass geometry (1 pass when not interlaced)
+    static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const int dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int npass = hd.interlace ? 7 : 1;
+    size_t total = 0;
+    size_t pass_off[7], pass_rb[7];
+    uint32_t pass_w[7], pass_h[7];
+    for (int p = 0; p < npass; ++p) {
+        pass_w[p] = hd.interlace ? (hd.w - xs[p] + dx[p] - 1) / dx[p] : hd.w;
+        pass_h[p] = hd.interlace ? (hd.h - ys[p] + dy[p] - 1) / dy[p] : hd.h;
+        if (hd.interlace && ((int)hd.w <= xs[p] || (int)hd.h <= ys[p])) pass_w[p] = pass_h[p] = 0;
+        pass_rb[p] = ((size_t)pass_w[p] * bits_pp + 7) / 8;
+        pass_off[p] = total;
+        if (pass_w[p] && pass_h[p]) total += (pass_rb[p] + 1) * pass_h[p];
+    }
+
+    std::vector<uint8_t> raw(total);
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
+        zs.next_in = idat.data();
+        zs.avail_in = (uInt)idat.size();
+        zs.next_out = raw.data();
+        zs.avail_out = (uInt)raw.size();
+        const int rc = inflate(&zs, Z_FINISH);
+        const size_t got = zs.total_out;
+        inflateEnd(&zs);
+        if ((rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) || got < total) { err = "corrupt PNG data"; return false; }
+    }
+
+    // output channel count, stb-style
+    int och;
+    if (hd.ctype == 3) och = have_trns ? 4 : 3;
+    else och = fch + ((have_trns && (hd.ctype == 0 || hd.ctype == 2)) ? 1 : 0);
+    out.width = (int)hd.w; out.height = (int)hd.h; out.channels = och;
+    out.pixels.assign((size_t)hd.w * hd.h * och, 0);
+
+    uint32_t key[3] = {0, 0, 0};
+    const bool keyed = have_trns && (hd.ctype == 0 || hd.ctype == 2);
+    if (keyed) {
+        if (trns.size() < (size_t)2 * fch) { err = "bad tRNS"; return false; }
+        for (int c = 0; c < fch; ++c) key[c] = (uint32_t)trns[2 * c] << 8 | trns[2 * c + 1];
+    }
+    static const int scale_lo[5] = {0, 255, 85, 0, 17};   // grey depth 1,2,4 -> 0..255
+
+    for (int p = 0; p < npass; ++p) {
+        if (!pass_w[p] || !pass_h[p]) continue;
+        uint8_t *base = raw.data() + pass_off[p];
+        if (!unfilter(base, pass_rb[p], pass_h[p], bpp, err)) return false;
+        for (uint32_t py = 0; py < pass_h[p]; ++py) {
+            const uint8_t *row = base + (size_t)py * (pass_rb[p] + 1) + 1;
+            const uint32_t oy = hd.interlace ? ys[p] + py * dy[p] : py;
+            for (uint32_t px = 0; px < pass_w[p]; ++px) {
+                const uint32_t ox = hd.interlace ? xs[p] + px * dx[p] : px;
+                uint8_t *o = out.pixels.data() + ((size_t)oy * hd.w + ox) * och;
+                if (hd.ctype == 3) {
+                    const uint32_t idx = sample_at(row, px, hd.depth);
+                    if ((size_t)idx * 3 + 2 < plte.size()) { o[0] = plte[idx * 3]; o[1] = plte[idx * 3 + 1]; o[2] = plte[idx * 3 + 2]; }
+                    if (och == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
+                    continue;
+                }
+                bool is_key = keyed;
+                for (int c = 0; c < fch; ++c) {
+                    const uint32_t v = sample_at(row, (size_t)px * fch + c, hd.depth);
+                    if (keyed && v != key[c]) is_key = false;
+                    o[c] = hd.depth == 16 ? (uint8_t)(v >> 8) : hd.depth == 8 ? (uint8_t)v : (uint8_t)(v * scale_lo[hd.depth]);
+                }
+                if (keyed) o[fch] = is_key ? 0 : 255;
+            }
+        }
+    }
+    return true;
+}
+
+// ---- binary PNM (P5 / P6, maxval 255) ---------------------------------------------------------------
+
+bool decode_pnm(const uint8_t *data, size_t size, GhImage &out, std::string &err)
+{
+    if (size < 3 || data[0] != 'P' || (data[1] != '5' && data[1] != '6')) { err = "not a binary PNM"; return false; }
+    const int ch = data[1] == '5' ? 1 : 3;
+    size_t pos = 2;
+    long vals[3];
+    for (int k = 0; k < 3; ++k) {
+        for (;;) {
+            while (pos < size && (data[pos] == ' ' || data[pos] == '\n' || data[pos] == '\r' || data[pos] == '\t')) ++pos;
+            if (pos < size && data[pos] == '#') { while (pos < size && data[pos] != '\n') ++pos; continue; }
+            break;
+        }
+        long v = 0; bool any = false;
+        while (pos < size && data[pos] >= '0' && data[pos] <= '9') { v = v * 10 + (data[pos] - '0'); ++pos; any = true; if (v > (1 << 30)) break; }
+        if (!any) { err = "bad PNM header"; return false; }
+        vals[k] = v;
+    }
+    ++pos;   // single whitespace after maxval
+    if (vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0) { err = "unsupported PNM (need maxval 255)"; return false; }
+    const size_t need = (size_t)vals[0] * vals[1] * ch;
+    if (pos + need > size) { err = "truncated PNM"; return false; }
+    out.width = (int)vals[0]; out.height = (int)vals[1]; out.channels = ch;
+    out.pixels.assign(data + pos, data + pos + need);
+    return true;
+}
+
+void put_chunk(std::vector<uint8_t> &f, const char *type, const uint8_t *body, size_t len)
+{
+    const uint8_t l[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len};
+    f.insert(f.end(), l, l + 4);
+    const size_t start = f.size();
+    f.insert(f.end(), type, type + 4);
+    if (len) f.insert(f.end(), body, body + len);
+    const uint32_t crc = (uint32_t)crc32(0L, f.data() + start, (uInt)(len + 4));
+    const uint8_t c[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+    f.insert(f.end(), c, c + 4);
+}
+
+}  // namespace
+
+bool gh_image_load_memory(const uint8_t *data, size_t size, GhImage &out, std::string &err)
+{
+    if (size >= 8 && data[0] == 0x89 && data[1] == 'P') return decode_png(data, size, out, err);
+    if (size >= 2 && data[0] == 0xFF && data[1] == 0xD8) return gh_jpeg_decode(data, size, out, err);
+    if (size >= 2 && data[0] == 'P' && (data[1] == '5' || data[1] == '6')) return decode_pnm(data, size, out, err);
+    err = "unknown image type";
+    return false;
+}
+
+bool gh_image_load(const std::string &path, GhImage &out, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open file"; return false; }
+    std::vector<uint8_t> buf;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    return gh_image_load_memory(buf.data(), buf.size(), out, err);
+}
+
+bool gh_image_write_png(const std::string &path, int width, int height, int channels, const uint8_t *pixels, std::string &err)
+{
+    if (width <= 0 || height <= 0 || channels < 1 || channels > 4 || !pixels) { err = "bad image"; return false; }
+    static const int ctype_of[5] = {0, 0, 4, 2, 6};
+    const size_t rb = (size_t)width * channels;
+    const int bpp = channels;
+
+    // adaptive filtering: per row keep the filter with the smallest sum of |signed residual|
+    std::vector<uint8_t> filtered((rb + 1) * (size_t)height);
+    std::vector<uint8_t> cand(rb), best(rb);
+    std::vector<uint8_t> zero(rb, 0);
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *cur = pixels + (size_t)y * rb;
+        const uint8_t *prev = y ? cur - rb : zero.data();
+        long best_cost = -1; int best_ft = 0;
+        for (int ft = 0; ft < 5; ++ft) {
+            long cost = 0;
+            for (size_t i = 0; i < rb; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0;
+                const int b = prev[i];
+                const int c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                switch (ft) { case 1: pred = a; break; case 2: pred = b; break; case 3: pred = (a + b) >> 1; break; case 4: pred = paeth(a, b, c); break; }
+                const uint8_t v = (uint8_t)(cur[i] - pred);
+                cand[i] = v;
+                cost += abs((int)(int8_t)v);
+            }
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ft = ft; best.swap(cand); }
+        }
+        uint8_t *dst = filtered.data() + (size_t)y * (rb + 1);
+        dst[0] = (uint8_t)best_ft;
+        memcpy(dst + 1, best.data(), rb);
+    }
+
+    const char *lv = getenv("GH_PNG_LEVEL");
+    const int level = lv ? atoi(lv) : 6;
+    uLongf zcap = compressBound((uLong)filtered.size());
+    std::vector<uint8_t> z(zcap);
+    if (compress2(z.data(), &zcap, filtered.data(), (uLong)filtered.size(), level) != Z_OK) { err = "zlib compress failed"; return false; }
+
+    std::vector<uint8_t> file;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    file.insert(file.end(), sig, sig + 8);
+    uint8_t ihdr[13] = {(uint8_t)(width >> 24), (uint8_t)(width >> 16), (uint8_t)(width >> 8), (uint8_t)width,
+                        (uint8_t)(height >> 24), (uint8_t)(height >> 16), (uint8_t)(height >> 8), (uint8_t)height,
+                        8, (uint8_t)ctype_of[channels], 0, 0, 0};
+    put_chunk(file, "IHDR", ihdr, 13);
+    put_chunk(file, "IDAT", z.data(), zcap);
+    put_chunk(file, "IEND", nullptr, 0);
+
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot open output file"; return false; }
+    const bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    if (fclose(f) != 0 || !ok) { err = "short write"; return false; }
+    return true;
+}

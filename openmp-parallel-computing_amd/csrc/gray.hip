@@ -1,0 +1,369 @@
+// gray.hip -- RGB8/RGBA8 -> luma kernels for gfx950 (MI355X), plus the plane extract / replicate
+// byte shuffles of the reference's Sobel driver.
+//
+// Replaces (paths relative to the reference repository):
+//   monolithic/src/parallel_to_grayscale.c:5-17   convert_to_grayscale  (k_gray_inplace*)
+//   monolithic/src/main_with_sobel.c:57-59        plane extract         (k_extract*)
+//   monolithic/src/main_with_sobel.c:65-73        plane replicate       (k_replicate*)
+//
+// Layout: a frame is one flat byte stream (pitch = width*channels, no padding, as in the
+// reference), so the kernels are 1-D.  Every lane owns 16 consecutive pixels:
+//   RGB8 : 48 B in  = 3 x global_load_dwordx4,  16 B out = 1 x global_store_dwordx4
+//   RGBA8: 64 B in  = 4 x global_load_dwordx4
+// 16 px * 3 B = 48 B keeps each lane's group 16-byte aligned, so the loads are full-width and a
+// wave covers 3 KiB of contiguous input per iteration.  Bound: HBM (3 R + 1 W bytes per pixel for
+// the plane variant, 3 R + 3 W in place); no LDS needed (no reuse), no MFMA (no contraction).
+#include "gh_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int PX_PER_LANE = 16;
+
+template <int MODE>
+__device__ __forceinline__ void luma16_rgb(const uint32_t (&w)[12], uint32_t (&lum)[16])
+{
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int o = 3 * p;
+        lum[p] = gh_luma<MODE>(gh_byte(w[o >> 2], o & 3), gh_byte(w[(o + 1) >> 2], (o + 1) & 3),
+                               gh_byte(w[(o + 2) >> 2], (o + 2) & 3));
+    }
+}
+
+__device__ __forceinline__ uint4 pack16(const uint32_t (&v)[16])
+{
+    uint4 o;
+    o.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    o.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+    o.z = v[8] | (v[9] << 8) | (v[10] << 16) | (v[11] << 24);
+    o.w = v[12] | (v[13] << 8) | (v[14] << 16) | (v[15] << 24);
+    return o;
+}
+
+__device__ __forceinline__ void load48(const uint4 *p, uint32_t (&w)[12])
+{
+    const uint4 a = p[0], b = p[1], c = p[2];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+}
+
+// ---- RGB8 -> plane, 16 px per lane -------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_rgb_to_plane(const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                             size_t ngroups)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        uint32_t w[12], lum[16];
+        load48(in + 3 * g, w);
+        luma16_rgb<MODE>(w, lum);
+        out[g] = pack16(lum);
+    }
+}
+
+// ---- RGBA8 -> plane ----------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_rgba_to_plane(const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                              size_t ngroups)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        uint32_t lum[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = in[4 * g + q];
+            const uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lum[4 * q + k] = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
+        }
+        out[g] = pack16(lum);
+    }
+}
+
+// ---- in place, reference ABI: R=G=B=luma, alpha untouched --------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb(uint4 *__restrict__ data, size_t ngroups)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        uint32_t w[12], lum[16], o[12];
+        load48(data + 3 * g, w);
+        luma16_rgb<MODE>(w, lum);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {   // output byte k of the 48 is lum[k / 3]
+            o[j] = lum[(4 * j) / 3] | (lum[(4 * j + 1) / 3] << 8) | (lum[(4 * j + 2) / 3] << 16) |
+                   (lum[(4 * j + 3) / 3] << 24);
+        }
+        data[3 * g + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+        data[3 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        data[3 * g + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgba(uint4 *__restrict__ data, size_t nquads)
+{
+    // one uint4 = 4 RGBA pixels
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nquads; q += stride) {
+        uint4 v = data[q];
+        uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t y = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
+            px[k] = (px[k] & 0xff000000u) | (y * 0x00010101u);
+        }
+        data[q] = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
+// ---- one pixel per lane: tails, unaligned buffers, channels 1/2 --------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_to_plane_px(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                            size_t first, size_t npix, int channels)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = first + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+        const uint8_t *p = in + i * channels;
+        out[i] = channels >= 3 ? (uint8_t)gh_luma<MODE>(p[0], p[1], p[2]) : p[0];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_px(uint8_t *__restrict__ data, size_t first, size_t npix,
+                                                           int channels)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = first + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+        uint8_t *p = data + i * channels;
+        const uint8_t y = (uint8_t)gh_luma<MODE>(p[0], p[1], p[2]);
+        p[0] = y; p[1] = y; p[2] = y;
+    }
+}
+
+// ---- luma of a grey plane: v -> lum(v,v,v) -----------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_of_plane(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                         size_t npix, int vec_ok)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    const size_t ngroups = vec_ok ? npix / 16 : 0;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        const uint4 v = reinterpret_cast<const uint4 *>(src)[g];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t lum[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const uint32_t b = gh_byte(w[p >> 2], p & 3);
+            lum[p] = gh_luma<MODE>(b, b, b);
+        }
+        reinterpret_cast<uint4 *>(dst)[g] = pack16(lum);
+    }
+    for (size_t i = ngroups * 16 + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+        const uint32_t b = src[i];
+        dst[i] = (uint8_t)gh_luma<MODE>(b, b, b);
+    }
+}
+
+// ---- plane extract / replicate -----------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_extract_rgb(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t ngroups)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        uint32_t w[12], v[16];
+        load48(in + 3 * g, w);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = gh_byte(w[(3 * p) >> 2], (3 * p) & 3);
+        out[g] = pack16(v);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_extract_px(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t first,
+                                                      size_t npix, int channels)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = first + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) out[i] = in[i * channels];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_replicate_rgb(const uint4 *__restrict__ plane, uint4 *__restrict__ img, size_t ngroups)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        const uint4 v = plane[g];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int p = (4 * j + b) / 3;
+                acc |= gh_byte(w[p >> 2], p & 3) << (8 * b);
+            }
+            o[j] = acc;
+        }
+        img[3 * g + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+        img[3 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        img[3 * g + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_replicate_px(const uint8_t *__restrict__ plane, uint8_t *__restrict__ img, size_t first,
+                                                        size_t npix, int channels)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = first + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+        uint8_t *p = img + i * channels;
+        const uint8_t v = plane[i];
+        p[0] = v;
+        if (channels >= 3) { p[1] = v; p[2] = v; }
+    }
+}
+
+// grid for a grid-stride 1-D kernel: enough blocks to cover `items`, capped so the tail of a very
+// large launch is absorbed by the stride loop (GH_GRAY_MAX_BLOCKS, tunable for experiments).
+inline unsigned grid_for(size_t items)
+{
+    static const size_t cap = [] {
+        const char *e = getenv("GH_GRAY_MAX_BLOCKS");
+        long v = e ? atol(e) : 0;
+        return (size_t)(v > 0 ? v : 1 << 20);
+    }();
+    size_t blocks = (items + BLOCK - 1) / BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, int channels, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(rgb && gray, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    size_t done = 0;
+    if ((channels == 3 || channels == 4) && gh_aligned16(rgb) && gh_aligned16(gray) && npix >= PX_PER_LANE) {
+        const size_t ngroups = npix / PX_PER_LANE;
+        const unsigned grid = grid_for(ngroups);
+        auto in = reinterpret_cast<const uint4 *>(rgb);
+        auto out = reinterpret_cast<uint4 *>(gray);
+        if (channels == 3) {
+            if (mode == GH_MODE_FMA) k_gray_rgb_to_plane<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
+            else k_gray_rgb_to_plane<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
+        } else {
+            if (mode == GH_MODE_FMA) k_gray_rgba_to_plane<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
+            else k_gray_rgba_to_plane<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
+        }
+        GH_LAUNCH_CHECK();
+        done = ngroups * PX_PER_LANE;
+    }
+    if (done < npix) {
+        const unsigned grid = grid_for(npix - done);
+        if (mode == GH_MODE_FMA) k_gray_to_plane_px<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(rgb, gray, done, npix, channels);
+        else k_gray_to_plane_px<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(rgb, gray, done, npix, channels);
+        GH_LAUNCH_CHECK();
+    }
+    return GH_OK;
+}
+
+int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
+    if (npix == 0 || channels < 3) return GH_OK;   // channels 1/2: undefined in the reference, no-op here
+    GH_REQUIRE(data, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    size_t done = 0;
+    if (gh_aligned16(data) && npix >= PX_PER_LANE) {
+        auto p = reinterpret_cast<uint4 *>(data);
+        if (channels == 3) {
+            const size_t ngroups = npix / PX_PER_LANE;
+            const unsigned grid = grid_for(ngroups);
+            if (mode == GH_MODE_FMA) k_gray_inplace_rgb<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(p, ngroups);
+            else k_gray_inplace_rgb<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(p, ngroups);
+            done = ngroups * PX_PER_LANE;
+        } else {
+            const size_t nquads = npix / 4;
+            const unsigned grid = grid_for(nquads);
+            if (mode == GH_MODE_FMA) k_gray_inplace_rgba<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(p, nquads);
+            else k_gray_inplace_rgba<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(p, nquads);
+            done = nquads * 4;
+        }
+        GH_LAUNCH_CHECK();
+    }
+    if (done < npix) {
+        const unsigned grid = grid_for(npix - done);
+        if (mode == GH_MODE_FMA) k_gray_inplace_px<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(data, done, npix, channels);
+        else k_gray_inplace_px<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(data, done, npix, channels);
+        GH_LAUNCH_CHECK();
+    }
+    return GH_OK;
+}
+
+int gh_gray_of_plane_dev(const uint8_t *src, uint8_t *dst, size_t npix, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(src && dst, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int vec_ok = gh_aligned16(src) && gh_aligned16(dst);
+    const unsigned grid = grid_for(vec_ok ? (npix + 15) / 16 : npix);
+    if (mode == GH_MODE_FMA) k_gray_of_plane<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(src, dst, npix, vec_ok);
+    else k_gray_of_plane<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(src, dst, npix, vec_ok);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+int gh_extract_plane_dev(const uint8_t *img, uint8_t *plane, size_t npix, int channels, gh_stream_t stream)
+{
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(img && plane, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    size_t done = 0;
+    if (channels == 3 && gh_aligned16(img) && gh_aligned16(plane) && npix >= PX_PER_LANE) {
+        const size_t ngroups = npix / PX_PER_LANE;
+        k_extract_rgb<<<grid_for(ngroups), BLOCK, 0, s>>>(reinterpret_cast<const uint4 *>(img), reinterpret_cast<uint4 *>(plane), ngroups);
+        GH_LAUNCH_CHECK();
+        done = ngroups * PX_PER_LANE;
+    }
+    if (done < npix) {
+        k_extract_px<<<grid_for(npix - done), BLOCK, 0, s>>>(img, plane, done, npix, channels);
+        GH_LAUNCH_CHECK();
+    }
+    return GH_OK;
+}
+
+int gh_replicate_plane_dev(const uint8_t *plane, uint8_t *img, size_t npix, int channels, gh_stream_t stream)
+{
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(img && plane, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    size_t done = 0;
+    if (channels == 3 && gh_aligned16(img) && gh_aligned16(plane) && npix >= PX_PER_LANE) {
+        const size_t ngroups = npix / PX_PER_LANE;
+        k_replicate_rgb<<<grid_for(ngroups), BLOCK, 0, s>>>(reinterpret_cast<const uint4 *>(plane), reinterpret_cast<uint4 *>(img), ngroups);
+        GH_LAUNCH_CHECK();
+        done = ngroups * PX_PER_LANE;
+    }
+    if (done < npix) {
+        k_replicate_px<<<grid_for(npix - done), BLOCK, 0, s>>>(plane, img, done, npix, channels);
+        GH_LAUNCH_CHECK();
+    }
+    return GH_OK;
+}
+
+}  // extern "C"

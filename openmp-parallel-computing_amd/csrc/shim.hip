@@ -1,0 +1,319 @@
+// shim.hip -- runtime, error reporting and the HOST-pointer side of the C ABI (include/grayhip.h):
+// the reference's own symbols convert_to_grayscale() / sobel_edge() and the CLI's per-pass
+// pipelines, implemented as H2D -> gfx950 kernels -> D2H.  No CPU fallback: if HIP or the GPU is
+// missing every entry point fails (the two void reference symbols print to stderr and abort).
+//
+// Reference call sites this file stands in for:
+//   monolithic/src/main.c:33-35             passes x convert_to_grayscale        -> gh_gray_passes_host
+//   monolithic/src/main_with_sobel.c:51-74  passes x (gray, extract, sobel, replicate) -> gh_pipeline_gray_sobel_*
+#include "gh_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+thread_local char g_err[768] = "";
+std::once_flag g_init_once;
+int g_init_rc = GH_OK;
+int g_device = -1;
+
+// grow-only device scratch for the host-pointer entry points (caller threads are serialised)
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return GH_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return gh_set_error(GH_ERR_HIP, "hipFree: %s", hipGetErrorString(e)); }
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return gh_set_error(GH_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e)); }
+        cap = n;
+        return GH_OK;
+    }
+};
+Scratch g_img, g_gray, g_edge;
+std::mutex g_host_mu;
+
+int do_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return gh_set_error(GH_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return gh_set_error(GH_ERR_ARG, "device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    GH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return gh_set_error(GH_ERR_NO_DEVICE, "device %d is %s; libgrayhip carries gfx950 code only", device, prop.gcnArchName);
+    GH_HIP_TRY(hipSetDevice(device));
+    GH_HIP_TRY(hipFree(nullptr));   // force context creation
+    g_device = device;
+    return GH_OK;
+}
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    int start(hipStream_t s)
+    {
+        GH_HIP_TRY(hipEventCreate(&a));
+        GH_HIP_TRY(hipEventCreate(&b));
+        GH_HIP_TRY(hipEventRecord(a, s));
+        return GH_OK;
+    }
+    int stop(hipStream_t s, double *seconds)
+    {
+        GH_HIP_TRY(hipEventRecord(b, s));
+        GH_HIP_TRY(hipEventSynchronize(b));
+        float ms = 0.f;
+        GH_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        if (seconds) *seconds = ms * 1e-3;
+        return GH_OK;
+    }
+    ~EventTimer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+}  // namespace
+
+int gh_set_error(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (getenv("GRAYHIP_VERBOSE")) fprintf(stderr, "grayhip: %s\n", g_err);
+    return status;
+}
+
+int gh_ensure_init()
+{
+    std::call_once(g_init_once, [] {
+        const char *e = getenv("GRAYHIP_DEVICE");
+        g_init_rc = do_init(e ? atoi(e) : 0);
+    });
+    if (g_init_rc != GH_OK && g_err[0] == 0) gh_set_error(g_init_rc, "HIP initialisation failed earlier in this process");
+    return g_init_rc;
+}
+
+extern "C" {
+
+int gh_init(int device)
+{
+    bool first = false;
+    std::call_once(g_init_once, [&] { first = true; g_init_rc = do_init(device); });
+    if (first || g_init_rc != GH_OK) return g_init_rc;
+    if (device != g_device) {   // re-target an already initialised process
+        int rc = do_init(device);
+        if (rc != GH_OK) return rc;
+    }
+    return GH_OK;
+}
+
+int gh_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+const char *gh_last_error(void) { return g_err; }
+
+const char *gh_version(void) { return "grayhip 0.1 (gfx950)"; }
+
+int gh_default_mode(void)
+{
+    const char *e = getenv("GRAYHIP_MODE");
+    return (e && (strcmp(e, "fma") == 0 || strcmp(e, "FMA") == 0)) ? GH_MODE_FMA : GH_MODE_IEEE;
+}
+
+int gh_malloc(void **dptr, size_t nbytes)
+{
+    GH_REQUIRE(dptr, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    GH_HIP_TRY(hipMalloc(dptr, nbytes ? nbytes : 1));
+    return GH_OK;
+}
+
+int gh_free(void *dptr)
+{
+    if (!dptr) return GH_OK;
+    GH_HIP_TRY(hipFree(dptr));
+    return GH_OK;
+}
+
+int gh_memset_dev(void *dptr, int value, size_t nbytes, gh_stream_t stream)
+{
+    if (nbytes == 0) return GH_OK;
+    GH_REQUIRE(dptr, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    GH_HIP_TRY(hipMemsetAsync(dptr, value, nbytes, (hipStream_t)stream));
+    return GH_OK;
+}
+
+int gh_copy_h2d(void *dst_dev, const void *src_host, size_t nbytes, gh_stream_t stream)
+{
+    if (nbytes == 0) return GH_OK;
+    GH_REQUIRE(dst_dev && src_host, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    GH_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return GH_OK;
+}
+
+int gh_copy_d2h(void *dst_host, const void *src_dev, size_t nbytes, gh_stream_t stream)
+{
+    if (nbytes == 0) return GH_OK;
+    GH_REQUIRE(dst_host && src_dev, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    GH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return GH_OK;
+}
+
+int gh_stream_sync(gh_stream_t stream)
+{
+    if (int rc = gh_ensure_init()) return rc;
+    GH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GH_OK;
+}
+
+// ---- device-resident pipeline ------------------------------------------------------------------
+
+int gh_pipeline_gray_sobel_dev(uint8_t *img, int width, int height, int channels, int passes, int mode, uint8_t *gray_ws,
+                               uint8_t *edge_ws, gh_stream_t stream)
+{
+    GH_REQUIRE(width >= 0 && height >= 0, "negative size");
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (passes < 1) passes = 1;   // main_with_sobel.c:44-45
+    const size_t npix = (size_t)width * height;
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(img && gray_ws && edge_ws, "null pointer");
+    for (int p = 0; p < passes; ++p) {
+        int rc;
+        if (p == 0) {
+            // gray in place + extract fused: the in-place luma write is dead, replicate overwrites R,G,B
+            rc = gh_gray_rgb8_to_plane_dev(img, gray_ws, npix, channels, mode, stream);
+        } else if (channels >= 3) {
+            // the image now holds (e,e,e): its luma is lum(e,e,e), not e (13 grey levels move in IEEE mode)
+            rc = gh_gray_of_plane_dev(edge_ws, gray_ws, npix, mode, stream);
+        } else {
+            hipError_t e = hipMemcpyAsync(gray_ws, edge_ws, npix, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            rc = e == hipSuccess ? GH_OK : gh_set_error(GH_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+        if (rc) return rc;
+        if ((rc = gh_sobel_u8_dev(gray_ws, edge_ws, width, height, stream))) return rc;
+    }
+    return gh_replicate_plane_dev(edge_ws, img, npix, channels, stream);
+}
+
+// ---- host-pointer entry points -----------------------------------------------------------------
+
+int gh_gray_passes_host(unsigned char *data, int width, int height, int channels, int passes, int mode, double *kernel_seconds)
+{
+    GH_REQUIRE(width >= 0 && height >= 0, "negative size");
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (kernel_seconds) *kernel_seconds = 0.0;
+    if (passes < 1) passes = 1;   // main.c:27-28
+    const size_t npix = (size_t)width * height, nbytes = npix * channels;
+    if (npix == 0 || channels < 3) return GH_OK;
+    GH_REQUIRE(data, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (int rc = g_img.reserve(nbytes)) return rc;
+    GH_HIP_TRY(hipMemcpy(g_img.p, data, nbytes, hipMemcpyHostToDevice));
+    EventTimer t;
+    if (int rc = t.start(nullptr)) return rc;
+    for (int p = 0; p < passes; ++p)
+        if (int rc = gh_gray_inplace_dev((uint8_t *)g_img.p, npix, channels, mode, nullptr)) return rc;
+    if (int rc = t.stop(nullptr, kernel_seconds)) return rc;
+    GH_HIP_TRY(hipMemcpy(data, g_img.p, nbytes, hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
+int gh_convert_to_grayscale_host(unsigned char *data, int width, int height, int channels, int mode)
+{
+    return gh_gray_passes_host(data, width, height, channels, 1, mode, nullptr);
+}
+
+int gh_sobel_edge_host(const unsigned char *src, unsigned char *dst, int width, int height)
+{
+    GH_REQUIRE(width >= 0 && height >= 0, "negative size");
+    if (width < 3 || height < 3) return GH_OK;   // no interior: the reference writes nothing
+    GH_REQUIRE(src && dst && src != dst, "null or aliased pointers");
+    if (int rc = gh_ensure_init()) return rc;
+    const size_t npix = (size_t)width * height;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (int rc = g_gray.reserve(npix)) return rc;
+    if (int rc = g_edge.reserve(npix)) return rc;
+    GH_HIP_TRY(hipMemcpy(g_gray.p, src, npix, hipMemcpyHostToDevice));
+    if (int rc = gh_sobel_u8_dev((const uint8_t *)g_gray.p, (uint8_t *)g_edge.p, width, height, nullptr)) return rc;
+    // interior only: the reference never touches dst's border (sobel.c:11-12)
+    GH_HIP_TRY(hipMemcpy2D(dst + width + 1, (size_t)width, (const uint8_t *)g_edge.p + width + 1, (size_t)width,
+                           (size_t)width - 2, (size_t)height - 2, hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
+int gh_pipeline_gray_sobel_host(unsigned char *img, int width, int height, int channels, int passes, int mode, double *kernel_seconds)
+{
+    GH_REQUIRE(width >= 0 && height >= 0, "negative size");
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (kernel_seconds) *kernel_seconds = 0.0;
+    const size_t npix = (size_t)width * height, nbytes = npix * channels;
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(img, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (int rc = g_img.reserve(nbytes)) return rc;
+    if (int rc = g_gray.reserve(npix)) return rc;
+    if (int rc = g_edge.reserve(npix)) return rc;
+    GH_HIP_TRY(hipMemcpy(g_img.p, img, nbytes, hipMemcpyHostToDevice));
+    EventTimer t;
+    if (int rc = t.start(nullptr)) return rc;
+    if (int rc = gh_pipeline_gray_sobel_dev((uint8_t *)g_img.p, width, height, channels, passes, mode, (uint8_t *)g_gray.p,
+                                            (uint8_t *)g_edge.p, nullptr))
+        return rc;
+    if (int rc = t.stop(nullptr, kernel_seconds)) return rc;
+    GH_HIP_TRY(hipMemcpy(img, g_img.p, nbytes, hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
+int gh_sum_rgb8_host(const unsigned char *rgb, size_t npix, uint64_t sums[3])
+{
+    GH_REQUIRE(sums, "null pointer");
+    sums[0] = sums[1] = sums[2] = 0;
+    if (npix == 0) return GH_OK;
+    GH_REQUIRE(rgb, "null pointer");
+    if (int rc = gh_ensure_init()) return rc;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (int rc = g_img.reserve(npix * 3)) return rc;
+    if (int rc = g_gray.reserve(64)) return rc;
+    GH_HIP_TRY(hipMemcpy(g_img.p, rgb, npix * 3, hipMemcpyHostToDevice));
+    GH_HIP_TRY(hipMemset(g_gray.p, 0, 3 * sizeof(uint64_t)));
+    if (int rc = gh_sum_rgb8_dev((const uint8_t *)g_img.p, npix, (uint64_t *)g_gray.p, nullptr)) return rc;
+    GH_HIP_TRY(hipMemcpy(sums, g_gray.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
+// ---- the reference's own symbols ---------------------------------------------------------------
+
+void convert_to_grayscale(unsigned char *data, int width, int height, int channels)
+{
+    if (gh_convert_to_grayscale_host(data, width, height, channels, gh_default_mode()) != GH_OK) {
+        fprintf(stderr, "grayhip: convert_to_grayscale failed: %s\n", gh_last_error());
+        abort();
+    }
+}
+
+void sobel_edge(const unsigned char *src, unsigned char *dst, int width, int height)
+{
+    if (gh_sobel_edge_host(src, dst, width, height) != GH_OK) {
+        fprintf(stderr, "grayhip: sobel_edge failed: %s\n", gh_last_error());
+        abort();
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Two layers, both thin over the C ABI (abi.py -> libgrayhip.so -> gfx950 kernels):
+
+* the reference's own functions, same names / argument meaning / in-place behaviour, on HOST
+  buffers (numpy uint8 arrays standing in for the C `unsigned char *`):
+      convert_to_grayscale(data, width, height, channels)      monolithic/include/parallel_to_grayscale.h:4
+      sobel_edge(src, dst, width, height)                      monolithic/include/sobel.h:3-5
+      gray_passes / pipeline_gray_sobel                        monolithic/src/main.c:33-35, main_with_sobel.c:51-74
+* device-resident operators on torch uint8 CUDA tensors (torch is only the allocator / stream
+  provider here), used by bench.py and the multi-GPU sharding code.
+
+Nothing here computes pixels in Python; a missing library or GPU raises GrayHipError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import MODE_FMA, MODE_IEEE, GrayHipError, check  # noqa: F401
+
+
+def _host_ptr(a: np.ndarray, writable: bool) -> int:
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or not a.flags["C_CONTIGUOUS"]:
+        raise GrayHipError("host buffers must be C-contiguous numpy uint8 arrays")
+    if writable and not a.flags["WRITEABLE"]:
+        raise GrayHipError("destination buffer is read-only")
+    return a.ctypes.data
+
+
+# ---- reference-named host functions ---------------------------------------------------------
+
+def convert_to_grayscale(data: np.ndarray, width: int, height: int, channels: int, mode: int | None = None) -> None:
+    """In place: R=G=B=(uchar)(0.299f*r+0.587f*g+0.114f*b), alpha untouched."""
+    if data.size < width * height * channels:
+        raise GrayHipError("buffer smaller than width*height*channels")
+    lib = abi.load()
+    m = lib.gh_default_mode() if mode is None else mode
+    check(lib.gh_convert_to_grayscale_host(_host_ptr(data, True), width, height, channels, m), "convert_to_grayscale")
+
+
+def sobel_edge(src: np.ndarray, dst: np.ndarray, width: int, height: int) -> None:
+    """Writes the interior of dst only (1<=x<w-1, 1<=y<h-1), like the reference."""
+    if src.size < width * height or dst.size < width * height:
+        raise GrayHipError("buffer smaller than width*height")
+    lib = abi.load()
+    check(lib.gh_sobel_edge_host(_host_ptr(src, False), _host_ptr(dst, True), width, height), "sobel_edge")
+
+
+def gray_passes(data: np.ndarray, width: int, height: int, channels: int, passes: int, mode: int = MODE_IEEE) -> float:
+    """main.c:33-35 -- `passes` x convert_to_grayscale on one upload; returns kernel seconds."""
+    secs = C.c_double(0.0)
+    check(abi.load().gh_gray_passes_host(_host_ptr(data, True), width, height, channels, passes, mode, C.byref(secs)),
+          "gray_passes")
+    return secs.value
+
+
+def pipeline_gray_sobel(img: np.ndarray, width: int, height: int, channels: int, passes: int = 1,
+                        mode: int = MODE_IEEE) -> float:
+    """main_with_sobel.c:51-74 -- `passes` x (gray, extract, sobel, replicate) in place; returns kernel seconds."""
+    secs = C.c_double(0.0)
+    check(abi.load().gh_pipeline_gray_sobel_host(_host_ptr(img, True), width, height, channels, passes, mode, C.byref(secs)),
+          "pipeline_gray_sobel")
+    return secs.value
+
+
+def sum_rgb(rgb: np.ndarray) -> list[int]:
+    """Exact per-channel sums of an RGB8 frame (old/parallel_avg_pixel.c restated)."""
+    s = (C.c_uint64 * 3)()
+    check(abi.load().gh_sum_rgb8_host(_host_ptr(rgb, False), rgb.size // 3, s), "sum_rgb")
+    return [int(s[0]), int(s[1]), int(s[2])]
+
+
+def avg_pixel(rgb: np.ndarray, avgs_in=(0, 0, 0)) -> list[int]:
+    """The reference's accumulate-then-divide: avgs = (avgs_in + 3*sum) / (3*N), C integer division."""
+    n = rgb.size // 3
+    sums = sum_rgb(rgb)
+    out = []
+    for a, s in zip(avgs_in, sums):
+        num = int(a) + 3 * s
+        q = abs(num) // (3 * n) if n else 0
+        out.append(q if num >= 0 else -q)
+    return out
+
+
+# ---- device-resident operators (torch uint8 CUDA tensors) ------------------------------------
+
+def _dev_ptr(t) -> int:
+    import torch
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
+        raise GrayHipError("device operands must be contiguous torch.uint8 CUDA tensors")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def init(device: int = 0) -> None:
+    check(abi.load().gh_init(device), "gh_init")
+
+
+def gray_to_plane(rgb, mode: int = MODE_IEEE, out=None):
+    """(h, w, c) uint8 -> (h, w) luma plane."""
+    import torch
+    h, w, c = rgb.shape
+    if out is None:
+        out = torch.empty((h, w), dtype=torch.uint8, device=rgb.device)
+    check(abi.load().gh_gray_rgb8_to_plane_dev(_dev_ptr(rgb), _dev_ptr(out), h * w, c, mode, _stream()), "gray_to_plane")
+    return out
+
+
+def gray_inplace(img, mode: int = MODE_IEEE):
+    h, w, c = img.shape
+    check(abi.load().gh_gray_inplace_dev(_dev_ptr(img), h * w, c, mode, _stream()), "gray_inplace")
+    return img
+
+
+def sobel(plane, out=None):
+    """(h, w) uint8 -> (h, w) Sobel magnitude, border = 0."""
+    import torch
+    h, w = plane.shape
+    if out is None:
+        out = torch.empty_like(plane)
+    check(abi.load().gh_sobel_u8_dev(_dev_ptr(plane), _dev_ptr(out), w, h, _stream()), "sobel")
+    return out
+
+
+def sobel_rows(buf, out, rows: int, top_is_border: bool, bottom_is_border: bool):
+    """Row band with halo storage: `buf` is (rows+2, w); rows 1..rows are the band, row 0 / rows+1 are
+    the halo rows (ignored when the corresponding edge is the frame border).  `out` is (rows, w)."""
+    w = buf.shape[1]
+    assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w)
+    check(abi.load().gh_sobel_u8_rows_dev(_dev_ptr(buf) + w, _dev_ptr(out), w, rows, int(top_is_border),
+                                          int(bottom_is_border), _stream()), "sobel_rows")
+    return out
+
+
+def gray_sobel_fused(rgb, mode: int = MODE_IEEE, out=None):
+    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane in one kernel (width % 16 == 0)."""
+    import torch
+    h, w, c = rgb.shape
+    if out is None:
+        out = torch.empty((h, w), dtype=torch.uint8, device=rgb.device)
+    check(abi.load().gh_gray_sobel_fused_rows_dev(_dev_ptr(rgb), _dev_ptr(out), w, h, c, mode, 1, 1, _stream()),
+          "gray_sobel_fused")
+    return out
+
+
+def gray_sobel_fused_rows(buf, out, rows: int, mode: int, top_is_border: bool, bottom_is_border: bool):
+    """Band form of the fused kernel: `buf` is (rows+2, w, c) with RGB halo rows 0 and rows+1."""
+    w, c = buf.shape[1], buf.shape[2]
+    assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w)
+    check(abi.load().gh_gray_sobel_fused_rows_dev(_dev_ptr(buf) + w * c, _dev_ptr(out), w, rows, c, mode,
+                                                  int(top_is_border), int(bottom_is_border), _stream()),
+          "gray_sobel_fused_rows")
+    return out
+
+
+def extract_plane(img, out=None):
+    import torch
+    h, w, c = img.shape
+    if out is None:
+        out = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    check(abi.load().gh_extract_plane_dev(_dev_ptr(img), _dev_ptr(out), h * w, c, _stream()), "extract_plane")
+    return out
+
+
+def replicate_plane(plane, img):
+    h, w, c = img.shape
+    check(abi.load().gh_replicate_plane_dev(_dev_ptr(plane), _dev_ptr(img), h * w, c, _stream()), "replicate_plane")
+    return img
+
+
+def gray_of_plane(plane, mode: int = MODE_IEEE, out=None):
+    import torch
+    if out is None:
+        out = torch.empty_like(plane)
+    check(abi.load().gh_gray_of_plane_dev(_dev_ptr(plane), _dev_ptr(out), plane.numel(), mode, _stream()), "gray_of_plane")
+    return out
+
+
+def conv3x3(rgb, kernel, norm: int, out=None):
+    import torch
+    h, w, c = rgb.shape
+    if c != 3:
+        raise GrayHipError("conv3x3 takes RGB8 frames")
+    if out is None:
+        out = torch.empty_like(rgb)
+    k = (C.c_int32 * 9)(*[int(v) for v in np.asarray(kernel).reshape(-1)])
+    check(abi.load().gh_conv3x3_rgb8_dev(_dev_ptr(rgb), _dev_ptr(out), w, h, k, int(norm), _stream()), "conv3x3")
+    return out
+
+
+def sum_rgb_dev(rgb):
+    """Device-resident exact channel sums -> python ints."""
+    import torch
+    sums = torch.zeros(3, dtype=torch.int64, device=rgb.device)
+    check(abi.load().gh_sum_rgb8_dev(_dev_ptr(rgb), rgb.numel() // 3, sums.data_ptr(), _stream()), "sum_rgb")
+    return [int(v) for v in sums.cpu().tolist()]
+
+
+def mean_gray_minmax(rgb, out=None):
+    import torch
+    if out is None:
+        out = torch.empty_like(rgb)
+    mm = torch.tensor([256, -1], dtype=torch.int32, device=rgb.device)
+    check(abi.load().gh_mean_gray_minmax_dev(_dev_ptr(rgb), _dev_ptr(out), rgb.numel() // 3, mm.data_ptr(), _stream()),
+          "mean_gray_minmax")
+    lo, hi = mm.cpu().tolist()
+    return out, int(lo), int(hi)
+
+
+def pipeline_gray_sobel_dev(img, passes: int = 1, mode: int = MODE_IEEE):
+    """Reference per-pass pipeline on a device-resident (h, w, c) image, in place."""
+    import torch
+    h, w, c = img.shape
+    gray = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    edge = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    check(abi.load().gh_pipeline_gray_sobel_dev(_dev_ptr(img), w, h, c, passes, mode, _dev_ptr(gray), _dev_ptr(edge),
+                                                _stream()), "pipeline_gray_sobel_dev")
+    return img, gray, edge
+
+
+def selftest_sobel_sqrt(m_max: int = 2 * 1020 * 1020) -> int:
+    bad = C.c_uint64(0)
+    check(abi.load().gh_selftest_sobel_sqrt(m_max, C.byref(bad)), "selftest_sobel_sqrt")
+    return int(bad.value)

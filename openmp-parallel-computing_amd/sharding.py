@@ -1,0 +1,139 @@
+"""Row sharding of a frame across GPUs (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference has no distributed layer (OpenMP shared memory only); this is
+the MI355X-native counterpart of its `#pragma omp parallel for` over rows for frames that span
+the 8 GPUs of a node:
+
+* grayscale (monolithic/src/parallel_to_grayscale.c:7-16) is embarrassingly parallel: each rank
+  converts its own contiguous block of rows, no communication;
+* Sobel (monolithic/src/sobel.c:10-24) needs one luma row from each neighbour: a `width`-byte
+  send/recv pair per neighbour (RCCL ncclSend/ncclRecv via torch.distributed P2P, grouped in one
+  batch), overlapped with the interior rows, which do not depend on the halo;
+* the channel sums (old/parallel_avg_pixel.c) are partial sums + one 24-byte all-reduce.
+
+The pixel work is delegated to a `backend` object so the same code runs on the GPU (HipBackend ->
+libgrayhip.so, the product path) and, in the CPU test-suite only, on a checker backend over gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+def row_partition(height: int, world: int) -> list[tuple[int, int]]:
+    """Contiguous row blocks [y0, y1) per rank; remainder rows go to the LAST ranks."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    base, rem = divmod(height, world)
+    out, y = [], 0
+    for r in range(world):
+        rows = base + (1 if r >= world - rem else 0)
+        out.append((y, y + rows))
+        y += rows
+    return out
+
+
+class HipBackend:
+    """Product backend: gfx950 kernels through the C ABI, tensors resident in HBM."""
+
+    name = "hip"
+
+    def __init__(self, mode: int = 0):
+        from . import hostapi
+        self.api = hostapi
+        self.mode = mode
+
+    def gray_to_plane(self, rgb, out):
+        return self.api.gray_to_plane(rgb, self.mode, out=out)
+
+    def sobel_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        return self.api.sobel_rows(buf, out, rows, top_is_border, bottom_is_border)
+
+    def sum_rgb(self, rgb):
+        return self.api.sum_rgb_dev(rgb)
+
+
+@dataclass
+class ShardGeometry:
+    rank: int
+    world: int
+    width: int
+    y0: int
+    y1: int
+
+    @property
+    def rows(self) -> int:
+        return self.y1 - self.y0
+
+    @property
+    def top_is_border(self) -> bool:
+        return self.rank == 0
+
+    @property
+    def bottom_is_border(self) -> bool:
+        return self.rank == self.world - 1
+
+
+class ShardedGraySobel:
+    """One rank's share of `gray -> halo exchange -> Sobel` on a row-sharded frame.
+
+    Buffers are allocated once: `luma` is (rows+2, width) with halo rows 0 and rows+1, `edge` is
+    (rows, width).  step(rgb_shard) enqueues everything asynchronously and returns `edge`.
+    """
+
+    def __init__(self, geom: ShardGeometry, backend, device, group=None, overlap: bool = True):
+        import torch
+        self.g = geom
+        self.backend = backend
+        self.group = group
+        self.overlap = overlap
+        self.luma = torch.zeros((geom.rows + 2, geom.width), dtype=torch.uint8, device=device)
+        self.edge = torch.empty((geom.rows, geom.width), dtype=torch.uint8, device=device)
+
+    # -- halo exchange: my first luma row goes up, my last goes down --------------------------
+    def _exchange_ops(self):
+        import torch.distributed as dist
+        g, buf = self.g, self.luma
+        ops = []
+        if not g.top_is_border:
+            ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
+        if not g.bottom_is_border:
+            ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
+        return ops
+
+    def step(self, rgb_shard):
+        import torch.distributed as dist
+        g = self.g
+        rows = g.rows
+        if rows == 0:
+            return self.edge
+        self.backend.gray_to_plane(rgb_shard, self.luma[1:rows + 1])
+        if g.world == 1:
+            self.backend.sobel_rows(self.luma, self.edge, rows, True, True)
+            return self.edge
+        ops = self._exchange_ops()
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if self.overlap and rows >= 3:
+            # rows 1..rows-2 of the band depend on local luma only
+            inner = self.luma[1:rows + 1]          # (rows, w): a band whose "halo" rows are band rows 0 / rows-1
+            self.backend.sobel_rows(inner, self.edge[1:rows - 1], rows - 2, False, False)
+            for wk in works:
+                wk.wait()
+            self.backend.sobel_rows(self.luma[0:3], self.edge[0:1], 1, g.top_is_border, False)
+            self.backend.sobel_rows(self.luma[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+        else:
+            for wk in works:
+                wk.wait()
+            self.backend.sobel_rows(self.luma, self.edge, rows, g.top_is_border, g.bottom_is_border)
+        return self.edge
+
+
+def allreduce_channel_sums(local_sums, device, group=None):
+    """Exact global per-channel sums from per-shard partial sums (3 x int64 all-reduce)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(local_sums, dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [int(v) for v in t.cpu().tolist()]

@@ -1,0 +1,307 @@
+"""Parity tests proper: the gfx950 kernels, called through the C ABI (libgrayhip.so), against the
+oracle, the compiled reference's known answers and the reference's golden image.  Bit-exact for
+every uint8 output and every integer sum -- there is no floating-point tolerance anywhere."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import make_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod(pkg):
+    import torch
+    pkg.hostapi.init(0)
+    return torch
+
+
+def dev(torch, a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def sha(t) -> str:
+    return hashlib.sha256(t.cpu().numpy().data).hexdigest()
+
+
+# ---- arithmetic building blocks ---------------------------------------------------------------
+
+def test_sqrt_mapping_exhaustive(pkg, torch_mod):
+    # every reachable m = gx^2 + gy^2 (and beyond): device mapping == min(255, isqrt(m))
+    assert pkg.hostapi.selftest_sobel_sqrt(2 * 1020 * 1020) == 0
+    assert pkg.hostapi.selftest_sobel_sqrt(1 << 23) == 0
+
+
+@pytest.mark.parametrize("mode_name,mode", [("IEEE", 0), ("FMA", 1)])
+def test_all_2pow24_triples(pkg, oracle, known, torch_mod, mode_name, mode):
+    """BASELINE config #2's shape: the 4096x4096 RGB cube holds every (r,g,b) exactly once."""
+    cube = oracle.frame_cube()
+    want = known[mode_name]["cube4096"]
+    d = dev(torch_mod, cube)
+    gray = pkg.hostapi.gray_to_plane(d, mode)
+    assert sha(gray) == want["gray"]
+    assert np.array_equal(gray.cpu().numpy(), oracle.gray_to_plane(cube, mode))
+    assert sha(pkg.hostapi.gray_inplace(d.clone(), mode)) == want["grayrgb"]
+    edge = pkg.hostapi.sobel(gray)
+    assert sha(edge) == want["edge"]
+    assert sha(pkg.hostapi.gray_sobel_fused(d, mode)) == want["edge"]
+
+
+@pytest.mark.parametrize("name", ["smooth4096", "rand1_4096", "smooth1021x517"])
+def test_known_answers_small(pkg, oracle, known, torch_mod, name):
+    spec = known["frames"][name]
+    frame = make_frame(oracle, name, spec)
+    d = dev(torch_mod, frame)
+    for mode_name, mode in (("IEEE", 0), ("FMA", 1)):
+        want = known[mode_name][name]
+        gray = pkg.hostapi.gray_to_plane(d, mode)
+        assert sha(gray) == want["gray"], (name, mode_name)
+        assert sha(pkg.hostapi.gray_inplace(d.clone(), mode)) == want["grayrgb"], (name, mode_name)
+        edge = pkg.hostapi.sobel(gray)
+        assert sha(edge) == want["edge"], (name, mode_name)
+        if spec["w"] % 16 == 0:
+            assert sha(pkg.hostapi.gray_sobel_fused(d, mode)) == want["edge"], (name, mode_name, "fused")
+    if name in known["channel_sums"]:
+        assert pkg.hostapi.sum_rgb_dev(d) == known["channel_sums"][name]
+
+
+@pytest.mark.parametrize("name", ["rand1_16384", "smooth16384"])
+def test_known_answers_full_size(pkg, oracle, known, torch_mod, name):
+    """BASELINE configs #3/#4 frame: 16384x16384 RGB8, hashes from the compiled reference."""
+    spec = known["frames"][name]
+    frame = make_frame(oracle, name, spec)
+    d = dev(torch_mod, frame)
+    del frame
+    want = known["IEEE"][name]
+    gray = pkg.hostapi.gray_to_plane(d, 0)
+    assert sha(gray) == want["gray"]
+    edge = pkg.hostapi.sobel(gray)
+    assert sha(edge) == want["edge"]
+    assert int(edge.sum(dtype=torch_mod.int64).item()) == want["edge_sum"]
+    fused = pkg.hostapi.gray_sobel_fused(d, 0)
+    assert torch_mod.equal(fused, edge)
+    del fused, edge
+    assert pkg.hostapi.sum_rgb_dev(d) == known["channel_sums"][name]
+    # FMA mode at full size (hash of the plane only)
+    assert sha(pkg.hostapi.gray_to_plane(d, 1, out=gray)) == known["FMA"][name]["gray"]
+    # in place at full size, then size-independent properties: R==G==B==plane, idempotent from pass 2
+    pkg.hostapi.gray_inplace(d, 0)
+    assert sha(d) == want["grayrgb"]
+    assert bool((d[..., 0] == d[..., 1]).all()) and bool((d[..., 0] == d[..., 2]).all())
+    p2 = pkg.hostapi.gray_inplace(d.clone(), 0)
+    p3 = pkg.hostapi.gray_inplace(p2.clone(), 0)
+    assert torch_mod.equal(p2, p3)
+
+
+def test_golden_image_crop(pkg, jpg_crop, torch_mod):
+    """The reference's only golden fixture: images/test_gray.png (crop committed under tests/golden)."""
+    d = dev(torch_mod, jpg_crop["rgb"])
+    out = pkg.hostapi.gray_inplace(d.clone(), 0).cpu().numpy()
+    assert np.array_equal(out, jpg_crop["golden_png"])
+    assert np.array_equal(pkg.hostapi.gray_to_plane(d, 1).cpu().numpy(), jpg_crop["gray_fma"])
+    edge = pkg.hostapi.sobel(dev(torch_mod, jpg_crop["gray_ieee"])).cpu().numpy()
+    assert np.array_equal(edge[1:-1, 1:-1], jpg_crop["edge_ieee"][1:-1, 1:-1])
+    assert not edge[0].any() and not edge[-1].any() and not edge[:, 0].any() and not edge[:, -1].any()
+
+
+# ---- geometry edge cases ------------------------------------------------------------------------
+
+SIZES = [(1, 1), (2, 2), (3, 3), (5, 2), (2, 9), (16, 3), (17, 4), (15, 15), (16, 16), (31, 33), (32, 34), (48, 1),
+         (1024, 32), (1040, 33), (1008, 31), (2048, 65), (1023, 70), (1025, 3), (4096, 2), (333, 77)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_sobel_shapes(pkg, oracle, torch_mod, w, h):
+    plane = oracle.frame_rand(w, h, 1, seed=w * 131 + h)[..., 0]
+    got = pkg.hostapi.sobel(dev(torch_mod, plane)).cpu().numpy()
+    assert np.array_equal(got, oracle.sobel(plane))
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("ch", [3, 4])
+def test_gray_shapes(pkg, oracle, torch_mod, w, h, ch):
+    img = oracle.frame_rand(w, h, ch, seed=w * 7 + h + ch)
+    d = dev(torch_mod, img)
+    for mode in (0, 1):
+        assert np.array_equal(pkg.hostapi.gray_to_plane(d, mode).cpu().numpy(), oracle.gray_to_plane(img, mode))
+        assert np.array_equal(pkg.hostapi.gray_inplace(d.clone(), mode).cpu().numpy(), oracle.gray_inplace(img, mode))
+    assert np.array_equal(pkg.hostapi.extract_plane(d).cpu().numpy(), oracle.extract_plane(img))
+    plane = oracle.frame_rand(w, h, 1, seed=99)[..., 0]
+    assert np.array_equal(pkg.hostapi.replicate_plane(dev(torch_mod, plane), d.clone()).cpu().numpy(),
+                          oracle.replicate_plane(plane, img))
+
+
+def test_gray_channels_1_and_2(pkg, oracle, torch_mod):
+    for ch in (1, 2):
+        img = oracle.frame_rand(37, 11, ch, seed=ch)
+        d = dev(torch_mod, img)
+        assert np.array_equal(pkg.hostapi.gray_to_plane(d, 0).cpu().numpy(), img[..., 0])
+        assert np.array_equal(pkg.hostapi.gray_inplace(d.clone(), 0).cpu().numpy(), img)   # documented no-op
+
+
+def test_unaligned_device_pointers(pkg, oracle, torch_mod):
+    """Buffers that are not 16-byte aligned take the per-pixel kernels; results are identical."""
+    w, h = 64, 9
+    img = oracle.frame_rand(w, h, 3, seed=5)
+    raw = torch_mod.zeros(w * h * 3 + 64, dtype=torch_mod.uint8, device="cuda")
+    for off in (1, 3, 8):
+        view = raw[off:off + w * h * 3].view(h, w, 3)
+        view.copy_(dev(torch_mod, img))
+        assert view.data_ptr() % 16 != 0
+        assert np.array_equal(pkg.hostapi.gray_to_plane(view, 0).cpu().numpy(), oracle.gray_to_plane(img, 0))
+        assert np.array_equal(pkg.hostapi.gray_inplace(view, 0).cpu().numpy(), oracle.gray_inplace(img, 0))
+    plane = oracle.frame_rand(w, h, 1, seed=6)[..., 0]
+    rawp = torch_mod.zeros(w * h + 64, dtype=torch_mod.uint8, device="cuda")
+    v = rawp[4:4 + w * h].view(h, w)
+    v.copy_(dev(torch_mod, plane))
+    assert np.array_equal(pkg.hostapi.sobel(v).cpu().numpy(), oracle.sobel(plane))
+
+
+@pytest.mark.parametrize("w,h,parts", [(1024, 96, 3), (2048, 67, 2), (48, 10, 4), (1024, 64, 8), (100, 30, 3)])
+def test_row_bands_equal_whole_frame(pkg, oracle, torch_mod, w, h, parts):
+    """Row sharding on one device: N bands with halo rows == the unsharded result, byte for byte."""
+    from importlib import import_module
+    sharding = import_module("openmp-parallel-computing_amd.sharding")
+    plane = oracle.frame_rand(w, h, 1, seed=w + h)[..., 0]
+    want = oracle.sobel(plane)
+    full = dev(torch_mod, plane)
+    got = torch_mod.empty_like(full)
+    for r, (y0, y1) in enumerate(sharding.row_partition(h, parts)):
+        rows = y1 - y0
+        if rows == 0:
+            continue
+        buf = torch_mod.zeros((rows + 2, w), dtype=torch_mod.uint8, device="cuda")
+        buf[1:rows + 1] = full[y0:y1]
+        if y0 > 0:
+            buf[0] = full[y0 - 1]
+        if y1 < h:
+            buf[rows + 1] = full[y1]
+        pkg.hostapi.sobel_rows(buf, got[y0:y1], rows, y0 == 0, y1 == h)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,ch", [(1024, 40, 3), (2064, 35, 3), (64, 5, 4), (16, 3, 3), (4096, 33, 4)])
+def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
+    img = oracle.frame_rand(w, h, ch, seed=w ^ h)
+    d = dev(torch_mod, img)
+    for mode in (0, 1):
+        want = oracle.sobel(oracle.gray_to_plane(img, mode))
+        assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want)
+    # band form with RGB halo rows
+    rows0 = h // 2
+    if rows0 >= 1 and h - rows0 >= 1:
+        want = oracle.sobel(oracle.gray_to_plane(img, 0))
+        got = torch_mod.empty((h, w), dtype=torch_mod.uint8, device="cuda")
+        for y0, y1 in ((0, rows0), (rows0, h)):
+            rows = y1 - y0
+            buf = torch_mod.zeros((rows + 2, w, ch), dtype=torch_mod.uint8, device="cuda")
+            buf[1:rows + 1] = d[y0:y1]
+            if y0 > 0:
+                buf[0] = d[y0 - 1]
+            if y1 < h:
+                buf[rows + 1] = d[y1]
+            pkg.hostapi.gray_sobel_fused_rows(buf, got[y0:y1], rows, 0, y0 == 0, y1 == h)
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ---- the reference's drivers and historic kernels -----------------------------------------------
+
+def test_pipeline_matches_reference_cli_fixtures(pkg, jpg_crop, cli_crop, torch_mod):
+    rgb = jpg_crop["rgb"]
+    rgba = np.dstack([rgb, cli_crop["rgba_alpha"]])
+    for passes in (1, 2, 3):
+        img, _, _ = pkg.hostapi.pipeline_gray_sobel_dev(dev(torch_mod, rgb), passes, 0)
+        out = img.cpu().numpy()
+        assert np.array_equal(out[..., 0], cli_crop[f"sobel_rgb_p{passes}_c0"]), passes
+        assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
+    for passes in (1, 2):
+        img, _, _ = pkg.hostapi.pipeline_gray_sobel_dev(dev(torch_mod, rgba), passes, 0)
+        out = img.cpu().numpy()
+        assert np.array_equal(out[..., 0], cli_crop[f"sobel_rgba_p{passes}_c0"]), passes
+        assert np.array_equal(out[..., 3], rgba[..., 3])
+
+
+@pytest.mark.parametrize("w,h,ch,passes,mode", [(333, 77, 3, 1, 0), (333, 77, 3, 3, 1), (64, 48, 4, 2, 0), (1040, 40, 3, 2, 0)])
+def test_pipeline_vs_oracle(pkg, oracle, torch_mod, w, h, ch, passes, mode):
+    img = oracle.frame_rand(w, h, ch, seed=passes * 17 + w)
+    want_img, _, want_edge = oracle.pipeline(img, passes, mode)
+    got_img, _, got_edge = pkg.hostapi.pipeline_gray_sobel_dev(dev(torch_mod, img), passes, mode)
+    assert np.array_equal(got_img.cpu().numpy(), want_img)
+    assert np.array_equal(got_edge.cpu().numpy(), want_edge)
+
+
+def test_host_pointer_shims(pkg, oracle, jpg_crop, cli_crop):
+    """The reference-named entry points on HOST buffers (what main.c-style callers link against)."""
+    rgb = jpg_crop["rgb"].copy()
+    h, w, c = rgb.shape
+    pkg.convert_to_grayscale(rgb, w, h, c)
+    assert np.array_equal(rgb, jpg_crop["golden_png"])
+    # the raw C symbol, void return, default mode
+    lib = pkg.abi.load()
+    raw = jpg_crop["rgb"].copy()
+    lib.convert_to_grayscale(raw.ctypes.data, w, h, c)
+    assert np.array_equal(raw, jpg_crop["golden_png"])
+    # sobel_edge writes the interior only
+    src = np.ascontiguousarray(jpg_crop["gray_ieee"])
+    dst = np.full_like(src, 0x5A)
+    pkg.sobel_edge(src, dst, w, h)
+    assert (dst[0] == 0x5A).all() and (dst[-1] == 0x5A).all() and (dst[:, 0] == 0x5A).all() and (dst[:, -1] == 0x5A).all()
+    assert np.array_equal(dst[1:-1, 1:-1], oracle.sobel(src)[1:-1, 1:-1])
+    tiny = np.full((2, 7), 9, dtype=np.uint8)
+    out = np.full((2, 7), 3, dtype=np.uint8)
+    pkg.sobel_edge(tiny, out, 7, 2)                       # no interior: nothing written
+    assert (out == 3).all()
+    # multi-pass drivers
+    img = jpg_crop["rgb"].copy()
+    secs = pkg.hostapi.gray_passes(img, w, h, c, 2, 0)
+    assert secs >= 0 and np.array_equal(img[..., 0], cli_crop["gray_rgb_p2_c0"])
+    img = jpg_crop["rgb"].copy()
+    pkg.hostapi.pipeline_gray_sobel(img, w, h, c, 2, 0)
+    assert np.array_equal(img[..., 0], cli_crop["sobel_rgb_p2_c0"])
+    rgba = np.ascontiguousarray(np.dstack([jpg_crop["rgb"], cli_crop["rgba_alpha"]]))
+    pkg.convert_to_grayscale(rgba, w, h, 4)
+    assert np.array_equal(rgba[..., 0], cli_crop["gray_rgba_p1_c0"]) and np.array_equal(rgba[..., 3], cli_crop["rgba_alpha"])
+
+
+@pytest.mark.parametrize("name", ["rand1_1024x1024", "rand1_1021x517"])
+def test_old_kernels(pkg, oracle, known, torch_mod, name):
+    ka = known["old_kernels"][name]
+    w, h = ka["w"], ka["h"]
+    img = oracle.frame_rand(w, h, 3, seed=1)
+    d = dev(torch_mod, img)
+    assert pkg.hostapi.sum_rgb_dev(d) == ka["sums"]
+    assert pkg.hostapi.sum_rgb(img) == ka["sums"]
+    assert pkg.hostapi.avg_pixel(img) == ka["avg"]
+    out, lo, hi = pkg.hostapi.mean_gray_minmax(d)
+    assert [lo, hi] == ka["mean_gray_minmax"] and sha(out) == ka["mean_gray_rgb"]
+    assert sha(pkg.hostapi.conv3x3(d, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16)) == ka["conv_gauss16"]
+    assert sha(pkg.hostapi.conv3x3(d, [1] * 9, 9)) == ka["conv_box9"]
+
+
+def test_conv3x3_signed_kernel_and_small_frames(pkg, oracle, torch_mod):
+    for w, h in ((1, 1), (2, 3), (17, 9), (64, 5)):
+        img = oracle.frame_rand(w, h, 3, seed=w * h)
+        d = dev(torch_mod, img)
+        for k, norm in (([0, -1, 0, -1, 5, -1, 0, -1, 0], 1), ([-1, -2, -1, 0, 0, 0, 1, 2, 1], 3), ([1] * 9, 9)):
+            assert np.array_equal(pkg.hostapi.conv3x3(d, k, norm).cpu().numpy(), oracle.conv3x3(img, k, norm)), (w, h, k)
+
+
+def test_gray_of_plane_moves_13_levels(pkg, known, torch_mod):
+    v = torch_mod.arange(256, dtype=torch_mod.uint8, device="cuda").repeat(5)
+    out = pkg.hostapi.gray_of_plane(v, 0)[:256].cpu().numpy()
+    moved = [int(i) for i in np.nonzero(out != np.arange(256))[0]]
+    assert moved == known["gray_of_gray_not_fixed_ieee"]
+
+
+def test_error_paths(pkg, torch_mod):
+    t = torch_mod.zeros((4, 4), dtype=torch_mod.uint8, device="cuda")
+    with pytest.raises(pkg.GrayHipError):
+        pkg.hostapi.sobel(t, out=t)                       # src == dst
+    with pytest.raises(pkg.GrayHipError):
+        pkg.hostapi.gray_to_plane(torch_mod.zeros((2, 2, 5), dtype=torch_mod.uint8, device="cuda"))
+    with pytest.raises(pkg.GrayHipError):
+        pkg.hostapi.gray_sobel_fused(torch_mod.zeros((4, 10, 3), dtype=torch_mod.uint8, device="cuda"))
+    empty = torch_mod.zeros((0, 16, 3), dtype=torch_mod.uint8, device="cuda")
+    assert pkg.hostapi.gray_to_plane(empty).numel() == 0
