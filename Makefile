@@ -20,7 +20,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisi
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/shim.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
-HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h
+HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h $(CSRC)/stream_core.h
 
 CXX      ?= g++
 CXXFLAGS := -O2 -std=c++17 -Wall -Iinclude -I$(CSRC)
@@ -57,3 +57,11 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib cli oracle clean
+
+# developer micro-benchmark (kernel variants; not shipped)
+ubench: bin/ubench
+bin/ubench: tools/ubench.hip tools/ubench_sobel.h tools/ubench_valu.h tools/ubench_stream.h $(HIP_HDRS) $(LIB)
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Iinclude -I$(CSRC) tools/ubench.hip \
+	    -L$(LIBDIR) -lgrayhip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+.PHONY: ubench

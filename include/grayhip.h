@@ -131,8 +131,11 @@ GH_API void convert_to_grayscale(unsigned char *data, int width, int height, int
 GH_API void sobel_edge(const unsigned char *src, unsigned char *dst, int width, int height);
 
 /* ---- self tests that need the device (used by tests/ through the C ABI) ------------------- */
-/* counts m in [0, m_max] for which the device's sqrt mapping differs from min(255, isqrt(m)) */
-GH_API int gh_selftest_sobel_sqrt(uint32_t m_max, uint64_t *mismatches);
+/* Runs every reachable Sobel gradient pair (gx, gy) in [-1020, 1020]^2 through one kernel family's
+ * magnitude mapping on the device and counts results that differ from min(255, isqrt(gx^2 + gy^2)).
+ * variant 0: strip-streaming packed-i16 core; 1: strip-streaming f32 core (fused kernel);
+ * 2: LDS-tile / per-pixel kernels. */
+GH_API int gh_selftest_sobel_mag(int variant, uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

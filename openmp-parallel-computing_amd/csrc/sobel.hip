@@ -1,28 +1,97 @@
 // sobel.hip -- 3x3 Sobel magnitude, u8 plane -> u8 plane, for gfx950 (MI355X).
 //
-// Replaces monolithic/src/sobel.c:6-25 (sobel_edge).  Bound: HBM, 1 R + 1 W byte per pixel; the
-// 3x3 reuse is served from LDS (tile + one-pixel halo, see sobel_tile.h), no MFMA.
+// Replaces monolithic/src/sobel.c:6-25 (sobel_edge).  Bound: HBM, 1 R + 1 W byte per pixel, no MFMA.
 //
-//   k_sobel_tiled : fast path (width % 16 == 0, 16-byte aligned planes)
-//   k_sobel_px    : one pixel per lane, any geometry / alignment (odd widths, tiny frames)
+//   k_sobel_stream : default fast path (width % 16 == 0, 16-byte aligned planes): strip streaming, 3x3 reuse in
+//                    registers, halo through DPP (stream_core.h)
+//   k_sobel_tiled  : the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h); GH_SOBEL_IMPL=tile
+//   k_sobel_px     : one pixel per lane, any geometry / alignment (odd widths, unaligned planes)
 #include "sobel_tile.h"
+#include "stream_core.h"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
 using namespace sobel_tile;
 
-// Is band-relative row yy backed by memory?  Rows -1 and `rows` are the halo rows of a shard.
-__device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int zero_bot)
+// ---- strip streaming ---------------------------------------------------------------------------------
+// R output rows per strip, C rows per load chunk; chunk ch+1 is in flight while chunk ch is computed.
+template <int R, int C>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
+                                                                    int rows, int groups_x, int zero_top, int zero_bot)
 {
-    return (yy >= 0 && yy < rows) || (yy == -1 && !zero_top) || (yy == rows && !zero_bot);
+    using namespace stream_core;
+    static_assert(C % 2 == 0, "chunk must be even: the h2 ring slot is the row parity");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    const int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;   // first pixel of this wave's strip
+    if (xw >= w) return;
+    const int x = xw + 16 * lane;
+    const int y0 = gy_i * R;
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    const float half = half_reg();
+    const bool in_frame = x < w;
+    const int hx = lane == 0 ? xw - 1 : xw + STRIP_PX;           // pixel just outside the strip, fetched by lanes 0 / 63
+    const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+
+    State16 st;
+    st.clear();
+    constexpr int NROWS = R + 2;
+    constexpr int NCH = (NROWS + C - 1) / C;
+    auto load_chunk = [&](int ch, uint4 (&q)[C], uint32_t (&hb)[C]) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int i = ch * C + j;
+            const int yy = y0 - 1 + i;
+            q[j] = make_uint4(0, 0, 0, 0);
+            hb[j] = 0;
+            if (i < NROWS && row_readable(yy, rows, zero_top, zero_bot)) {
+                const uint8_t *rowp = src + (ptrdiff_t)yy * w;
+                if (in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
+                if (hvalid) hb[j] = rowp[hx];
+            }
+        }
+    };
+    auto compute_chunk = [&](int ch, const uint4 (&q)[C], const uint32_t (&hb)[C]) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int i = ch * C + j;
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[j].w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            if (lane == 0) ql = hb[j] << 24;
+            if (lane == 63) qr = hb[j];
+            uint4 out = (j & 1) ? row16<1>(st, q[j], ql, qr, half) : row16<0>(st, q[j], ql, qr, half);
+            if (i >= 2 && i < NROWS) {
+                const int y = y0 + i - 2;
+                if (x == 0) out.x &= 0xffffff00u;            // frame column 0
+                if (x + 15 == w - 1) out.w &= 0x00ffffffu;   // frame column w-1
+                if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+                if (in_frame && y < rows) store_stream(reinterpret_cast<uint4 *>(dst + (size_t)y * w + x), out);
+            }
+        }
+    };
+    uint4 qa[C], qb[C];
+    uint32_t ha[C], hb2[C];
+    load_chunk(0, qa, ha);
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ch += 2) {
+        load_chunk(ch + 1, qb, hb2);
+        compute_chunk(ch, qa, ha);
+        load_chunk(ch + 2, qa, ha);
+        if (ch + 1 < NCH) compute_chunk(ch + 1, qb, hb2);
+    }
 }
+
+using stream_core::row_readable;
 
 __global__ __launch_bounds__(BLOCK) void k_sobel_tiled(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
                                                        int rows, int tiles_x, int zero_top, int zero_bot)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[LDS_BYTES];
 
-    const unsigned t = remap_tile(blockIdx.x, gridDim.x);
+    const unsigned t = blockIdx.x;
     const int x0 = (int)(t % (unsigned)tiles_x) * TW;
     const int y0 = (int)(t / (unsigned)tiles_x) * TH;
 
@@ -69,19 +138,31 @@ __global__ __launch_bounds__(BLOCK) void k_sobel_px(const uint8_t *__restrict__ 
     }
 }
 
-__global__ void k_selftest_sqrt(uint32_t m_max, unsigned long long *mismatches)
+// every reachable gradient pair (gx, gy) in [-1020, 1020]^2 through the magnitude mapping of one core
+//   variant 0: stream_core::mag_pack_rtz (packed-i16 core, MODE = RTZ)   variant 1: stream_core::mag_pack_rne (f32 core)
+//   variant 2: gh_sobel_mag on m = gx^2 + gy^2 (LDS-tile and per-pixel kernels)
+__global__ void k_selftest_mag(int variant, unsigned long long *mismatches)
 {
+    if (variant == 0) __builtin_amdgcn_s_setreg(0x0801, 3);
+    const float half = stream_core::half_reg();
+    constexpr int SPAN = 2041;
+    const size_t n = (size_t)SPAN * SPAN;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     unsigned long long bad = 0;
-    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m <= m_max; m += stride) {
-        // exact integer square root by bisection on r*r <= m
-        uint32_t lo = 0, hi = 65535;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int gx = (int)(i / SPAN) - 1020, gy = (int)(i % SPAN) - 1020;
+        const uint32_t m = (uint32_t)(gx * gx + gy * gy);
+        uint32_t lo = 0, hi = 2047;   // exact integer square root by bisection
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
-            if ((unsigned long long)mid * mid <= m) lo = mid; else hi = mid - 1;
+            if (mid * mid <= m) lo = mid; else hi = mid - 1;
         }
         const uint32_t want = lo > 255 ? 255 : lo;
-        if (gh_sobel_mag((int)m) != want) ++bad;
+        uint32_t got;
+        if (variant == 0) got = stream_core::mag_pack_rtz((float)gx, (float)gy, half, 0, 0u) & 0xffu;
+        else if (variant == 1) got = stream_core::mag_pack_rne((float)gx, (float)gy, half, 0, 0u) & 0xffu;
+        else got = gh_sobel_mag((int)m);
+        if (got != want) ++bad;
     }
     if (bad) atomicAdd(mismatches, bad);
 }
@@ -100,7 +181,14 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     if (int rc = gh_ensure_init()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
-    if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst)) {
+    static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
+    if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst) && !use_tile) {
+        constexpr int R = 16, C = 2;
+        const int groups_x = (width + stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK - 1) / (stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK);
+        const long long nb = (long long)groups_x * ((rows + R - 1) / R);
+        GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
+        k_sobel_stream<R, C><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
+    } else if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst)) {
         const int tiles_x = (width + TW - 1) / TW;
         const int tiles_y = (rows + TH - 1) / TH;
         const long long nt = (long long)tiles_x * tiles_y;
@@ -120,14 +208,15 @@ int gh_sobel_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, gh_
     return gh_sobel_u8_rows_dev(src, dst, width, height, 1, 1, stream);
 }
 
-int gh_selftest_sobel_sqrt(uint32_t m_max, uint64_t *mismatches)
+int gh_selftest_sobel_mag(int variant, uint64_t *mismatches)
 {
     GH_REQUIRE(mismatches, "null pointer");
+    GH_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
     if (int rc = gh_ensure_init()) return rc;
     unsigned long long *d = nullptr;
     GH_HIP_TRY(hipMalloc(&d, sizeof(*d)));
     GH_HIP_TRY(hipMemset(d, 0, sizeof(*d)));
-    k_selftest_sqrt<<<1024, 256>>>(m_max, d);
+    k_selftest_mag<<<1024, 256>>>(variant, d);
     GH_LAUNCH_CHECK();
     unsigned long long h = 0;
     GH_HIP_TRY(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));

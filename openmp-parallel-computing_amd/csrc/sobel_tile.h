@@ -36,14 +36,11 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2);
-// give each XCD one contiguous run of tiles so vertically adjacent tiles (which share halo rows)
-// meet in the same L2.  Speed only -- any mapping is correct.
-__device__ __forceinline__ unsigned remap_tile(unsigned bid, unsigned nblocks)
-{
-    if (nblocks % GH_NUM_XCD) return bid;
-    return (bid % GH_NUM_XCD) * (nblocks / GH_NUM_XCD) + bid / GH_NUM_XCD;
-}
+// Tile order: plain row-major blockIdx.  An XCD-aware remap (each XCD gets one contiguous run of tiles, so that
+// vertically adjacent tiles share an L2) was measured on MI355X and REMOVED: it made every row-strided kernel
+// slower (strip copy 0.115 ms vs 0.095 ms on a 16384^2 plane) because it concentrates each XCD on a distant
+// region instead of spreading concurrent requests over the HBM channels; halo re-reads are only 0.2 % of the
+// traffic (profiles/r1_first/pmc_hbm_traffic.json), so there was nothing to gain.
 
 // Horizontal stage of one staged row for this lane's 16 pixels.
 // q[0..3] = the lane's 16 pixels, ql = dword holding pixel x-1 in its top byte, qr = dword holding

@@ -1,0 +1,175 @@
+// stream_core.h -- the "strip streaming" Sobel cores for gfx950 (MI355X), shared by sobel.hip and fused.hip.
+//
+// Reference arithmetic: monolithic/src/sobel.c:14-22
+//   gx = -tl - 2l - bl + tr + 2r + br ;  gy = tl + 2t + tr - bl - 2b - br ;  dst = min(255, (int)sqrtf(gx*gx + gy*gy))
+//
+// Geometry: one wavefront owns a strip 1024 px wide (64 lanes x 16 px = one dwordx4 per lane per row) and
+// walks down R rows; the 4 waves of a workgroup sit side by side (4 KiB of every row).  The 3x3 reuse
+// lives in registers as a rolling window, the one-pixel horizontal halo comes from the neighbour lanes
+// (DPP wave_shr/wave_shl) and, for lanes 0 and 63, from a 1-byte global load.  No LDS, no barrier:
+// measured on MI355X the LDS-tile form (sobel_tile.h) and this form are both bound by the same
+// (row-strided) HBM access pattern, and this one needs fewer instructions per pixel (kernels).
+//
+// Separable form (identical integers to the reference):
+//   per input row:   h1[x] = p[x+1] - p[x-1]               h2[x] = p[x-1] + 2 p[x] + p[x+1]
+//   per output row:  gx = h1[y-1] + 2 h1[y] + h1[y+1]      gy = h2[y-1] - h2[y+1]
+//   rolling state:   c[y] = h1[y-1] + h1[y]  ->  gx = c[y] + c[y+1]   (h1p, cp) ; h2 ring of two rows
+//
+// Two cores:
+//   row16  packed 2 x i16 (v_pk_* ops), float tail under MODE.fp_round = toward-zero: 32 state VGPRs.
+//          Used by the plane -> plane kernel, which contains no rounding-sensitive float op.
+//   rowf   all-f32 (integers < 2^24 are exact); rounding-mode independent tail.  Used by the fused kernel,
+//          whose luma arithmetic needs round-to-nearest.
+#pragma once
+
+#include "gh_common.h"
+
+namespace stream_core {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+
+constexpr int STRIP_PX = 1024;          // pixels per wave per row
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+
+// a*2 + c on packed u16 as ONE v_pk_mad_u16 (hipcc would emit a shift and an add)
+__device__ __forceinline__ s16x2 pk_mad2(s16x2 a, s16x2 c)
+{
+    uint32_t d;
+    const uint32_t two = 0x00020002u;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(uint32_t, a)), "s"(two), "v"(__builtin_bit_cast(uint32_t, c)));
+    return as_s16x2(d);
+}
+
+// sqrt(gx^2 + gy^2 + 0.5) with the inner fma forced to one v_fma_f32 (hipcc would emit v_mov 0.5 + v_fmac).
+// Exact inputs: |gx|,|gy| <= 1020, so gx^2 + gy^2 + 0.5 < 2^22 is exact in float32.
+__device__ __forceinline__ float root_half(float fx, float fy, float half)
+{
+    float t;
+    asm("v_fma_f32 %0, %1, %1, %2" : "=v"(t) : "v"(fy), "v"(half));
+    return __builtin_amdgcn_sqrtf(__builtin_fmaf(fx, fx, t));
+}
+
+// Magnitude byte, variant RTZ: requires MODE.fp_round(f32) = toward zero.  v_sqrt_f32 is accurate to 1 ulp;
+// sqrt(m + 0.5) is never within 9e-4 of an integer for results <= 256 (|sqrt(k^2 +- 0.5) - k| >= 0.25/k), so
+// truncation gives floor(sqrt(m)) and v_cvt_pk_u8_f32 (which truncates under RTZ and saturates at 255)
+// gives min(255, isqrt(m)).  gh_selftest_sobel_mag(0) checks every reachable (gx, gy) on the device.
+__device__ __forceinline__ uint32_t mag_pack_rtz(float fx, float fy, float half, int byte, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(root_half(fx, fy, half), byte, acc);
+}
+
+// Variant RNE (default rounding): round-to-nearest of sqrt(m + 0.5) - 0.5 is floor(sqrt(m)) by the same
+// margin argument (the value is at least 9e-4 away from k +- 0.5).  gh_selftest_sobel_mag(1) checks it.
+__device__ __forceinline__ uint32_t mag_pack_rne(float fx, float fy, float half, int byte, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(root_half(fx, fy, half) - half, byte, acc);
+}
+
+// ---- packed-i16 core -----------------------------------------------------------------------------
+struct State16 {
+    s16x2 h1p[8], cp[8], h2r[2][8];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { h1p[k] = as_s16x2(0u); cp[k] = as_s16x2(0u); h2r[0][k] = as_s16x2(0u); h2r[1][k] = as_s16x2(0u); }
+    }
+};
+
+// One input row for this lane's 16 pixels: qv = the 16 pixels, ql holds pixel x-1 in its top byte, qr holds
+// pixel x+16 in its low byte.  Returns the output row that this input row completes (window rows i-2, i-1, i);
+// meaningful from the third row on.  PAR = row index parity (selects the h2 ring slot; must be static).
+template <int PAR>
+__device__ __forceinline__ uint4 row16(State16 &st, const uint4 &qv, uint32_t ql, uint32_t qr, float half)
+{
+    const uint32_t q[6] = {ql, qv.x, qv.y, qv.z, qv.w, qr};
+    s16x2 o[9], e[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t cur = q[j + 1];
+        e[2 * j] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c010c00u));        // (p[4j],   p[4j+1])
+        e[2 * j + 1] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c030c02u));    // (p[4j+2], p[4j+3])
+        o[2 * j] = as_s16x2(__builtin_amdgcn_perm(cur, q[j], 0x0c040c03u));      // (p[4j-1], p[4j])
+        o[2 * j + 1] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c020c01u));    // (p[4j+1], p[4j+2])
+    }
+    o[8] = as_s16x2(__builtin_amdgcn_perm(q[5], q[4], 0x0c040c03u));             // (p[15], p[16])
+    uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const s16x2 h1 = o[k + 1] - o[k];
+        const s16x2 h2 = pk_mad2(e[k], o[k] + o[k + 1]);
+        const s16x2 c = st.h1p[k] + h1;
+        const s16x2 gx = st.cp[k] + c;
+        const s16x2 gy = st.h2r[PAR][k] - h2;
+        st.h1p[k] = h1; st.cp[k] = c; st.h2r[PAR][k] = h2;
+#pragma unroll
+        for (int el = 0; el < 2; ++el) {
+            const int p = 2 * k + el;
+            const float fx = (float)(int)(el ? gx.y : gx.x), fy = (float)(int)(el ? gy.y : gy.x);
+            r[p >> 2] = mag_pack_rtz(fx, fy, half, p & 3, r[p >> 2]);
+        }
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// ---- f32 core ------------------------------------------------------------------------------------
+struct StateF {
+    float h1p[16], cp[16], h2r[2][16];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h1p[k] = 0.f; cp[k] = 0.f; h2r[0][k] = 0.f; h2r[1][k] = 0.f; }
+    }
+};
+
+// p[0..17] = luma at x-1 .. x+16 as integer-valued floats
+template <int PAR>
+__device__ __forceinline__ uint4 rowf(StateF &st, const float (&p)[18], float half)
+{
+    float s[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) s[k] = p[k] + p[k + 1];
+    uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float h1 = p[k + 2] - p[k];
+        const float h2 = s[k] + s[k + 1];
+        const float c = st.h1p[k] + h1;
+        const float gx = st.cp[k] + c;
+        const float gy = st.h2r[PAR][k] - h2;
+        st.h1p[k] = h1; st.cp[k] = c; st.h2r[PAR][k] = h2;
+        r[k >> 2] = mag_pack_rne(gx, gy, half, k & 3, r[k >> 2]);
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// streaming (read-once / write-once) 16-byte accesses: `nt` keeps these lines from displacing reusable data in L2
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream(const uint4 *p)
+{
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_stream(uint4 *p, const uint4 v)
+{
+    u32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+}
+
+// 0.5f kept in a VGPR (opaque to the optimiser) so the fma above can take it as a register operand
+__device__ __forceinline__ float half_reg()
+{
+    float h = 0.5f;
+    asm volatile("" : "+v"(h));
+    return h;
+}
+
+// band-relative row yy readable?  rows -1 and `rows` are the halo rows of a shard
+__device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int zero_bot)
+{
+    return (yy >= 0 && yy < rows) || (yy == -1 && !zero_top) || (yy == rows && !zero_bot);
+}
+
+}  // namespace stream_core

@@ -225,7 +225,8 @@ def pipeline_gray_sobel_dev(img, passes: int = 1, mode: int = MODE_IEEE):
     return img, gray, edge
 
 
-def selftest_sobel_sqrt(m_max: int = 2 * 1020 * 1020) -> int:
+def selftest_sobel_mag(variant: int) -> int:
+    """Exhaustive device check of one kernel family's magnitude mapping over all (gx, gy); returns #mismatches."""
     bad = C.c_uint64(0)
-    check(abi.load().gh_selftest_sobel_sqrt(m_max, C.byref(bad)), "selftest_sobel_sqrt")
+    check(abi.load().gh_selftest_sobel_mag(variant, C.byref(bad)), "selftest_sobel_mag")
     return int(bad.value)

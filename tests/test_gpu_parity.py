@@ -28,10 +28,10 @@ def sha(t) -> str:
 
 # ---- arithmetic building blocks ---------------------------------------------------------------
 
-def test_sqrt_mapping_exhaustive(pkg, torch_mod):
-    # every reachable m = gx^2 + gy^2 (and beyond): device mapping == min(255, isqrt(m))
-    assert pkg.hostapi.selftest_sobel_sqrt(2 * 1020 * 1020) == 0
-    assert pkg.hostapi.selftest_sobel_sqrt(1 << 23) == 0
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_magnitude_mapping_exhaustive(pkg, torch_mod, variant):
+    # every reachable gradient pair (gx, gy) in [-1020, 1020]^2: device mapping == min(255, isqrt(gx^2 + gy^2))
+    assert pkg.hostapi.selftest_sobel_mag(variant) == 0
 
 
 @pytest.mark.parametrize("mode_name,mode", [("IEEE", 0), ("FMA", 1)])
