@@ -22,25 +22,34 @@ namespace {
 using namespace sobel_tile;
 using stream_core::row_readable;
 
-// luma of one pixel as an integer-valued float: trunc(y) == (float)(unsigned char)y for 0 <= y <= 255
-// (same arithmetic as gh_luma, minus the float->int->float round trip)
+// luma of two pixels as integer-valued floats (packed f32: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32):
+// trunc(y) == (float)(unsigned char)y for 0 <= y <= 255; same arithmetic as gh_luma, minus the float->int->float
+// round trip.  IEEE mode must not be contracted; the FMA mode uses explicit fused multiply-adds.
+template <int MODE>
+__device__ __forceinline__ stream_core::f32x2 luma_f2(stream_core::f32x2 r, stream_core::f32x2 g, stream_core::f32x2 b)
+{
+#pragma clang fp contract(off)
+    using stream_core::f32x2;
+    const f32x2 cr = {0.299f, 0.299f}, cg = {0.587f, 0.587f}, cb = {0.114f, 0.114f};
+    f32x2 y;
+    if (MODE == GH_MODE_FMA) {
+        f32x2 t = cg * g;
+        t = __builtin_elementwise_fma(cr, r, t);
+        y = __builtin_elementwise_fma(cb, b, t);
+    } else {
+        const f32x2 s = cr * r + cg * g;
+        y = s + cb * b;
+    }
+    y.x = stream_core::opaque(__builtin_truncf(y.x));
+    y.y = stream_core::opaque(__builtin_truncf(y.y));
+    return y;
+}
+
 template <int MODE>
 __device__ __forceinline__ float luma_f(uint32_t r, uint32_t g, uint32_t b)
 {
-#pragma clang fp contract(off)
-    const float fr = (float)r, fg = (float)g, fb = (float)b;
-    float y;
-    if (MODE == GH_MODE_FMA) {
-        float t = 0.587f * fg;
-        t = __builtin_fmaf(0.299f, fr, t);
-        y = __builtin_fmaf(0.114f, fb, t);
-    } else {
-        const float s = 0.299f * fr + 0.587f * fg;
-        y = s + 0.114f * fb;
-    }
-    y = __builtin_truncf(y);
-    asm("" : "+v"(y));   // opaque: keeps the optimiser from turning the f32 adds below into (half-rate) integer ops
-    return y;
+    const stream_core::f32x2 y = luma_f2<MODE>(stream_core::f32x2{(float)r, 0.f}, stream_core::f32x2{(float)g, 0.f}, stream_core::f32x2{(float)b, 0.f});
+    return y.x;
 }
 
 // R output rows per strip, C rows per load chunk
@@ -59,38 +68,42 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
     if (xw >= w) return;
     const int x = xw + 16 * lane;
     const int y0 = gy_i * R;
-    const float half = half_reg();
+    const f32x2 half2 = half2_reg();
     const bool in_frame = x < w;
-    const int nvec = (xw + STRIP_PX <= w) ? NV * 64 : (w - xw) * CH / 16;   // 16-byte vectors of this strip row inside the frame
+    const bool full = xw + STRIP_PX <= w;
+    const int nvec = full ? NV * 64 : (w - xw) * CH / 16;                    // 16-byte vectors of this strip row inside the frame
     const int hx = lane == 0 ? xw - 1 : xw + STRIP_PX;
     const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
 
-    StateF st;
+    StateF2 st;
     st.clear();
     uint4 *sw = reinterpret_cast<uint4 *>(slab[wave]);
     const uint4 *sr = reinterpret_cast<const uint4 *>(slab[wave] + 16 * CH * lane);
 
     constexpr int NROWS = R + 2;
-    constexpr int NCH = (NROWS + C - 1) / C;
+    static_assert(NROWS % C == 0, "R + 2 must be a multiple of the chunk");
+    constexpr int NCH = NROWS / C;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
         uint4 v[C][NV];
         uint32_t hp[C][3];
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const int i = ch * C + j;
-            const int yy = y0 - 1 + i;
+            const int yy = clamp_row(y0 - 1 + ch * C + j, rows, zero_top, zero_bot);   // always a readable row
+            const uint8_t *rowb = rgb + ((ptrdiff_t)yy * w) * CH;
+            const uint4 *rowp = reinterpret_cast<const uint4 *>(rowb + (size_t)xw * CH);
+            if (full) {                                   // wave-uniform: the whole strip row is inside the frame
 #pragma unroll
-            for (int k = 0; k < NV; ++k) v[j][k] = make_uint4(0, 0, 0, 0);
-            hp[j][0] = hp[j][1] = hp[j][2] = 0;
-            if (i < NROWS && row_readable(yy, rows, zero_top, zero_bot)) {
-                const uint8_t *rowb = rgb + ((ptrdiff_t)yy * w) * CH;
-                const uint4 *rowp = reinterpret_cast<const uint4 *>(rowb + (size_t)xw * CH);
+                for (int k = 0; k < NV; ++k) v[j][k] = load_stream(rowp + 64 * k + lane);
+            } else {
 #pragma unroll
-                for (int k = 0; k < NV; ++k)
+                for (int k = 0; k < NV; ++k) {
+                    v[j][k] = make_uint4(0, 0, 0, 0);
                     if (64 * k + lane < nvec) v[j][k] = load_stream(rowp + 64 * k + lane);
-                if (hvalid) { const uint8_t *h = rowb + (size_t)hx * CH; hp[j][0] = h[0]; hp[j][1] = h[1]; hp[j][2] = h[2]; }
+                }
             }
+            hp[j][0] = hp[j][1] = hp[j][2] = 0;
+            if (hvalid) { const uint8_t *h = rowb + (size_t)hx * CH; hp[j][0] = h[0]; hp[j][1] = h[1]; hp[j][2] = h[2]; }
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -103,23 +116,35 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
 #pragma unroll
             for (int k = 0; k < NV; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
             __builtin_amdgcn_wave_barrier();
-            float p[18];
+            // pair layout: G[m] = (luma[m-1], luma[m+7]), m = 1..8 from this lane's pixels (m-1, m+7)
+            f32x2 G[10];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int m = 0; m < 8; ++m) {
+                f32x2 r2, g2, b2;
                 if (CH == 3) {
-                    const int o = 3 * k;
-                    p[k + 1] = luma_f<MODE>(gh_byte(wv[o >> 2], o & 3), gh_byte(wv[(o + 1) >> 2], (o + 1) & 3), gh_byte(wv[(o + 2) >> 2], (o + 2) & 3));
+                    const int o0 = 3 * m, o1 = 3 * (m + 8);
+                    r2 = f32x2{(float)gh_byte(wv[o0 >> 2], o0 & 3), (float)gh_byte(wv[o1 >> 2], o1 & 3)};
+                    g2 = f32x2{(float)gh_byte(wv[(o0 + 1) >> 2], (o0 + 1) & 3), (float)gh_byte(wv[(o1 + 1) >> 2], (o1 + 1) & 3)};
+                    b2 = f32x2{(float)gh_byte(wv[(o0 + 2) >> 2], (o0 + 2) & 3), (float)gh_byte(wv[(o1 + 2) >> 2], (o1 + 2) & 3)};
                 } else {
-                    p[k + 1] = luma_f<MODE>(gh_byte(wv[k], 0), gh_byte(wv[k], 1), gh_byte(wv[k], 2));
+                    r2 = f32x2{(float)gh_byte(wv[m], 0), (float)gh_byte(wv[m + 8], 0)};
+                    g2 = f32x2{(float)gh_byte(wv[m], 1), (float)gh_byte(wv[m + 8], 1)};
+                    b2 = f32x2{(float)gh_byte(wv[m], 2), (float)gh_byte(wv[m + 8], 2)};
                 }
+                G[m + 1] = luma_f2<MODE>(r2, g2, b2);
             }
             const float hl = luma_f<MODE>(hp[j][0], hp[j][1], hp[j][2]);
-            float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, p[16]), 0x138, 0xf, 0xf, false));
-            float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, p[1]), 0x130, 0xf, 0xf, false));
+            // strip halo: pixel x-1 is the left lane's pixel 15 (G[8].y), pixel x+16 the right lane's pixel 0 (G[1].x)
+            // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element expression reads
+            //  element 0 of the vector with this hipcc, which silently turned G[8].y into G[8].x)
+            const float own15 = G[8].y, own0 = G[1].x;
+            float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own15), 0x138, 0xf, 0xf, false));
+            float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own0), 0x130, 0xf, 0xf, false));
             if (lane == 0) pl = hl;
             if (lane == 63) pr = hl;
-            p[0] = pl; p[17] = pr;
-            uint4 out = (j & 1) ? rowf<1>(st, p, half) : rowf<0>(st, p, half);
+            G[0] = f32x2{pl, G[8].x};        // (p[-1], p[7])
+            G[9] = f32x2{G[1].y, pr};        // (p[8],  p[16])
+            uint4 out = (j & 1) ? rowf2<1>(st, G, half2) : rowf2<0>(st, G, half2);
             if (i >= 2 && i < NROWS) {
                 const int y = y0 + i - 2;
                 if (x == 0) out.x &= 0xffffff00u;

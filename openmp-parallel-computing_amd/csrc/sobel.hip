@@ -18,12 +18,17 @@ using namespace sobel_tile;
 
 // ---- strip streaming ---------------------------------------------------------------------------------
 // R output rows per strip, C rows per load chunk; chunk ch+1 is in flight while chunk ch is computed.
-template <int R, int C>
+// CORE 0: packed-i16 row step (stream_core::row16); CORE 1: packed-f32 pair-layout row step (rowf2).  Both run with
+// MODE.fp_round = toward zero: this kernel has no rounding-sensitive float op (all sums are exact integers).
+template <int R, int C, int CORE>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
                                                                     int rows, int groups_x, int zero_top, int zero_bot)
 {
     using namespace stream_core;
     static_assert(C % 2 == 0, "chunk must be even: the h2 ring slot is the row parity");
+    constexpr int NROWS = R + 2;
+    static_assert(NROWS % C == 0, "R + 2 must be a multiple of the chunk");
+    constexpr int NCH = NROWS / C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
     const int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;   // first pixel of this wave's strip
@@ -32,26 +37,26 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
     const int y0 = gy_i * R;
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const float half = half_reg();
+    const f32x2 half2 = {half, half};
     const bool in_frame = x < w;
+    const bool full = xw + STRIP_PX <= w;                        // wave-uniform: no lane predication needed
     const int hx = lane == 0 ? xw - 1 : xw + STRIP_PX;           // pixel just outside the strip, fetched by lanes 0 / 63
     const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
 
-    State16 st;
-    st.clear();
-    constexpr int NROWS = R + 2;
-    constexpr int NCH = (NROWS + C - 1) / C;
+    State16 st16;
+    StateF2 stf;
+    if (CORE == 0) st16.clear(); else stf.clear();
+
     auto load_chunk = [&](int ch, uint4 (&q)[C], uint32_t (&hb)[C]) {
+        if (ch >= NCH) return;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const int i = ch * C + j;
-            const int yy = y0 - 1 + i;
-            q[j] = make_uint4(0, 0, 0, 0);
+            const int yy = clamp_row(y0 - 1 + ch * C + j, rows, zero_top, zero_bot);   // always a readable row
+            const uint8_t *rowp = src + (ptrdiff_t)yy * w;
+            if (full) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
+            else { q[j] = make_uint4(0, 0, 0, 0); if (in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x)); }
             hb[j] = 0;
-            if (i < NROWS && row_readable(yy, rows, zero_top, zero_bot)) {
-                const uint8_t *rowp = src + (ptrdiff_t)yy * w;
-                if (in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
-                if (hvalid) hb[j] = rowp[hx];
-            }
+            if (hvalid) hb[j] = rowp[hx];
         }
     };
     auto compute_chunk = [&](int ch, const uint4 (&q)[C], const uint32_t (&hb)[C]) {
@@ -62,8 +67,21 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
             uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
             if (lane == 0) ql = hb[j] << 24;
             if (lane == 63) qr = hb[j];
-            uint4 out = (j & 1) ? row16<1>(st, q[j], ql, qr, half) : row16<0>(st, q[j], ql, qr, half);
-            if (i >= 2 && i < NROWS) {
+            uint4 out;
+            if (CORE == 0) {
+                out = (j & 1) ? row16<1>(st16, q[j], ql, qr, half) : row16<0>(st16, q[j], ql, qr, half);
+            } else {
+                // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
+                const uint32_t lo[2] = {q[j].x, q[j].y}, hi[2] = {q[j].z, q[j].w};
+                f32x2 G[10];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+                G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
+                G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
+                out = (j & 1) ? rowf2<1, 1>(stf, G, half2) : rowf2<0, 1>(stf, G, half2);
+            }
+            if (i >= 2) {
                 const int y = y0 + i - 2;
                 if (x == 0) out.x &= 0xffffff00u;            // frame column 0
                 if (x + 15 == w - 1) out.w &= 0x00ffffffu;   // frame column w-1
@@ -184,10 +202,12 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
     if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst) && !use_tile) {
         constexpr int R = 16, C = 2;
+        static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
         const int groups_x = (width + stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK - 1) / (stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK);
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        k_sobel_stream<R, C><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
+        if (core == 0) k_sobel_stream<R, C, 0><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
+        else k_sobel_stream<R, C, 1><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
     } else if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst)) {
         const int tiles_x = (width + TW - 1) / TW;
         const int tiles_y = (rows + TH - 1) / TH;

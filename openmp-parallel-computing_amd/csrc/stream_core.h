@@ -144,6 +144,62 @@ __device__ __forceinline__ uint4 rowf(StateF &st, const float (&p)[18], float ha
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+
+// ---- packed-f32 core ("pair layout") --------------------------------------------------------------
+// Measured on MI355X every wave64 VALU instruction costs ~4 cycles in these kernels, so instructions per
+// pixel is what counts; v_pk_{add,mul,fma}_f32 do two pixels per instruction when both operands sit in aligned
+// 64-bit register pairs.  Pairing pixel m with pixel m+8 of the lane's 16 makes every stencil neighbour pair
+// aligned too:  G[m] = (p[m-1], p[m+7]) for m = 0..9  (p[-1] and p[16] are the strip halo), so
+//   h1 pair k = G[k+2] - G[k],   h2 pair k = (G[k]+G[k+1]) + (G[k+1]+G[k+2])        (pixels k and k+8, k = 0..7)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct StateF2 {
+    f32x2 h1p[8], cp[8], h2r[2][8];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { h1p[k] = f32x2{0.f, 0.f}; cp[k] = f32x2{0.f, 0.f}; h2r[0][k] = f32x2{0.f, 0.f}; h2r[1][k] = f32x2{0.f, 0.f}; }
+    }
+};
+
+// RTZ = 1: the kernel runs with MODE.fp_round = toward zero (allowed only when it contains no rounding-sensitive
+// float op), so v_cvt_pk_u8_f32 floors by itself and the "- 0.5" is not needed.
+template <int PAR, int RTZ = 0>
+__device__ __forceinline__ uint4 rowf2(StateF2 &st, const f32x2 (&G)[10], f32x2 half2)
+{
+    f32x2 s[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) s[m] = G[m] + G[m + 1];
+    uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2 h1 = G[k + 2] - G[k];
+        const f32x2 h2 = s[k] + s[k + 1];
+        const f32x2 c = st.h1p[k] + h1;
+        const f32x2 gx = st.cp[k] + c;
+        const f32x2 gy = st.h2r[PAR][k] - h2;
+        st.h1p[k] = h1; st.cp[k] = c; st.h2r[PAR][k] = h2;
+        const f32x2 m = __builtin_elementwise_fma(gx, gx, __builtin_elementwise_fma(gy, gy, half2));   // exact: < 2^22
+        f32x2 f;
+        f.x = __builtin_amdgcn_sqrtf(m.x);
+        f.y = __builtin_amdgcn_sqrtf(m.y);
+        if (!RTZ) f = f - half2;                                            // see mag_pack_rne / mag_pack_rtz
+        r[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(f.x, k & 3, r[k >> 2]);              // pixel k
+        r[2 + (k >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(f.y, k & 3, r[2 + (k >> 2)]);  // pixel k + 8
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// opaque(): stops the optimiser from proving a float is a small integer and rewriting the f32 adds as integer/SDWA ops
+__device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
+
+__device__ __forceinline__ f32x2 half2_reg()
+{
+    f32x2 h = {0.5f, 0.5f};
+    asm volatile("" : "+v"(h));
+    return h;
+}
+
 // streaming (read-once / write-once) 16-byte accesses: `nt` keeps these lines from displacing reusable data in L2
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_stream(const uint4 *p)
@@ -164,6 +220,15 @@ __device__ __forceinline__ float half_reg()
     float h = 0.5f;
     asm volatile("" : "+v"(h));
     return h;
+}
+
+// Row index to LOAD for band-relative row yy: rows outside the readable range are clamped onto a readable row
+// instead of being zero-filled -- every output row that would see the substitute is a frame-border row and is
+// written as 0 anyway, and unconditional loads need no per-row zero fill / predication.
+__device__ __forceinline__ int clamp_row(int yy, int rows, int zero_top, int zero_bot)
+{
+    const int lo = zero_top ? 0 : -1, hi = zero_bot ? rows - 1 : rows;
+    return yy < lo ? lo : (yy > hi ? hi : yy);
 }
 
 // band-relative row yy readable?  rows -1 and `rows` are the halo rows of a shard

@@ -36,7 +36,11 @@ template <int NT> __device__ __forceinline__ void stg(uint4 *p, const uint4 v)
 }
 
 __device__ int g_remap = 1;     // XCD-aware tile order on/off (UB_REMAP=0|1)
-__device__ __forceinline__ unsigned ub_remap(unsigned bid, unsigned n) { return g_remap ? sobel_tile::remap_tile(bid, n) : bid; }
+__device__ __forceinline__ unsigned ub_remap(unsigned bid, unsigned n)
+{
+    if (!g_remap || (n % 8)) return bid;
+    return (bid % 8) * (n / 8) + bid / 8;     // each XCD gets one contiguous run of tiles
+}
 
 static int ITERS = 20, ROUNDS = 7;
 

@@ -142,8 +142,8 @@ __device__ __forceinline__ float lumaf(uint32_t r, uint32_t g, uint32_t b)
     return opaque(__builtin_truncf(y));     // == (float)(unsigned char)y for 0 <= y <= 255
 }
 
-template <int R, int C, int NT>
-__global__ __launch_bounds__(256) void k_fused_stream_f32(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ dst, int w, int rows, int groups_x)
+template <int R, int C, int NT, int PF = 0, int LB = 1>
+__global__ __launch_bounds__(256, LB) void k_fused_stream_f32(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ dst, int w, int rows, int groups_x)
 {
     static_assert(C % 2 == 0, "chunk must be even");
     __shared__ __attribute__((aligned(16))) uint8_t slab[4][3072];
@@ -156,10 +156,11 @@ __global__ __launch_bounds__(256) void k_fused_stream_f32(const uint8_t *__restr
     if (xw >= w) return;
     float half = 0.5f;
     asm volatile("" : "+v"(half));
-    const bool full = xw + 1024 <= w;          // whole wave span inside the frame (w % 16 == 0 assumed)
+    const bool full = xw + 1024 <= w;
     const bool in_frame = x < w;
     const int hx = lane == 0 ? xw - 1 : xw + 1024;
     const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+    const int nvec = full ? 192 : (w - xw) * 3 / 16;
 
     SobelState st;
 #pragma unroll
@@ -168,39 +169,38 @@ __global__ __launch_bounds__(256) void k_fused_stream_f32(const uint8_t *__restr
     const uint4 *sr = reinterpret_cast<const uint4 *>(slab[wave] + 48 * lane);
 
     constexpr int NCH = (R + 2 + C - 1) / C;
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-        uint4 a[C], b[C], c[C];
-        uint32_t hr[C], hg[C], hbl[C];
+    struct Chunk { uint4 a[C], b[C], c[C]; uint32_t hr[C], hg[C], hbl[C]; };
+    auto load_chunk = [&](int ch, Chunk &k) {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int yy = y0 - 1 + ch * C + j;
-            a[j] = b[j] = c[j] = make_uint4(0, 0, 0, 0);
-            hr[j] = hg[j] = hbl[j] = 0;
+            k.a[j] = k.b[j] = k.c[j] = make_uint4(0, 0, 0, 0);
+            k.hr[j] = k.hg[j] = k.hbl[j] = 0;
             if (yy >= 0 && yy < rows && ch * C + j < R + 2) {
                 const uint4 *rowp = reinterpret_cast<const uint4 *>(rgb + ((size_t)yy * w + xw) * 3);
-                const int nvec = full ? 192 : (w - xw) * 3 / 16;     // 16-byte vectors available in this span
-                if (lane < nvec) a[j] = ldg<NT>(rowp + lane);
-                if (64 + lane < nvec) b[j] = ldg<NT>(rowp + 64 + lane);
-                if (128 + lane < nvec) c[j] = ldg<NT>(rowp + 128 + lane);
-                if (hvalid) { const uint8_t *hp = rgb + ((size_t)yy * w + hx) * 3; hr[j] = hp[0]; hg[j] = hp[1]; hbl[j] = hp[2]; }
+                if (lane < nvec) k.a[j] = ldg<NT>(rowp + lane);
+                if (64 + lane < nvec) k.b[j] = ldg<NT>(rowp + 64 + lane);
+                if (128 + lane < nvec) k.c[j] = ldg<NT>(rowp + 128 + lane);
+                if (hvalid) { const uint8_t *hp = rgb + ((size_t)yy * w + hx) * 3; k.hr[j] = hp[0]; k.hg[j] = hp[1]; k.hbl[j] = hp[2]; }
             }
         }
+    };
+    auto compute_chunk = [&](int ch, const Chunk &k) {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int i = ch * C + j;
-            sw[lane] = a[j]; sw[64 + lane] = b[j]; sw[128 + lane] = c[j];
+            sw[lane] = k.a[j]; sw[64 + lane] = k.b[j]; sw[128 + lane] = k.c[j];
             __builtin_amdgcn_wave_barrier();
             const uint4 u0 = sr[0], u1 = sr[1], u2 = sr[2];
             __builtin_amdgcn_wave_barrier();
             const uint32_t wv[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
             float p[18];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int o = 3 * k;
-                p[k + 1] = lumaf<0>(gh_byte(wv[o >> 2], o & 3), gh_byte(wv[(o + 1) >> 2], (o + 1) & 3), gh_byte(wv[(o + 2) >> 2], (o + 2) & 3));
+            for (int q = 0; q < 16; ++q) {
+                const int o = 3 * q;
+                p[q + 1] = lumaf<0>(gh_byte(wv[o >> 2], o & 3), gh_byte(wv[(o + 1) >> 2], (o + 1) & 3), gh_byte(wv[(o + 2) >> 2], (o + 2) & 3));
             }
-            const float hl = lumaf<0>(hr[j], hg[j], hbl[j]);
+            const float hl = lumaf<0>(k.hr[j], k.hg[j], k.hbl[j]);
             float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, p[16]), 0x138, 0xf, 0xf, false));
             float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, p[1]), 0x130, 0xf, 0xf, false));
             if (lane == 0) pl = hl;
@@ -214,6 +214,24 @@ __global__ __launch_bounds__(256) void k_fused_stream_f32(const uint8_t *__restr
                 if (y == 0 || y == rows - 1) out = make_uint4(0, 0, 0, 0);
                 if (in_frame && y < rows) stg<NT>(reinterpret_cast<uint4 *>(dst + (size_t)y * w + x), out);
             }
+        }
+    };
+    if (PF) {
+        Chunk ka, kb;
+        load_chunk(0, ka);
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ch += 2) {
+            load_chunk(ch + 1, kb);
+            compute_chunk(ch, ka);
+            load_chunk(ch + 2, ka);
+            if (ch + 1 < NCH) compute_chunk(ch + 1, kb);
+        }
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+            Chunk k;
+            load_chunk(ch, k);
+            compute_chunk(ch, k);
         }
     }
 }
@@ -268,7 +286,9 @@ static void bench_stream(int W, int H)
     add("fused shipping (libgrayhip)", [=] { gh_gray_sobel_fused_rows_dev(rgb, out, W, H, 3, 0, 1, 1, nullptr); }, ref, 4.0 * npix);
     add("split shipping gray+sobel", [=] { gh_gray_rgb8_to_plane_dev(rgb, gray, npix, 3, 0, nullptr); gh_sobel_u8_dev(gray, out, W, H, nullptr); }, ref, 4.0 * npix);
 #define FF(R_, C_, NT_) add("fused f32 stream R" #R_ " C" #C_ " nt" #NT_, [=] { k_fused_stream_f32<R_, C_, NT_><<<gx * ((H + R_ - 1) / R_), 256>>>(rgb, out, W, H, gx); }, ref, 4.0 * npix)
-    FF(16, 2, 0); FF(32, 2, 0); FF(32, 4, 0); FF(64, 2, 0); FF(64, 4, 0); FF(16, 2, 1); FF(32, 2, 1); FF(32, 4, 1); FF(64, 4, 1);
+    FF(16, 2, 1); FF(32, 2, 1); FF(32, 4, 1); FF(64, 2, 1);
+#define FP(R_, C_, NT_, PF_, LB_) add("fused f32 stream R" #R_ " C" #C_ " nt" #NT_ " pf" #PF_ " lb" #LB_, [=] { k_fused_stream_f32<R_, C_, NT_, PF_, LB_><<<gx * ((H + R_ - 1) / R_), 256>>>(rgb, out, W, H, gx); }, ref, 4.0 * npix)
+    FP(32, 2, 1, 1, 1); FP(16, 2, 1, 1, 1); FP(64, 2, 1, 1, 1); FP(32, 4, 1, 1, 1); FP(32, 2, 1, 1, 2); FP(32, 2, 1, 0, 2); FP(32, 2, 1, 1, 3); FP(32, 2, 1, 0, 3); FP(32, 2, 0, 1, 1); FP(8, 2, 1, 1, 1);
     run_table("fused gray+sobel (3R+1W B/px)", vs, (double)npix);
     CK(hipFree(src)); CK(hipFree(ref)); CK(hipFree(out)); CK(hipFree(rgb)); CK(hipFree(gray));
 }
