@@ -53,7 +53,7 @@ __device__ __forceinline__ float luma_f(uint32_t r, uint32_t g, uint32_t b)
 }
 
 // R output rows per strip, C rows per load chunk
-template <int MODE, int CH, int R, int C>
+template <int MODE, int CH, int R, int C, int ROLL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w,
                                                                     int rows, int groups_x, int zero_top, int zero_bot)
 {
@@ -72,8 +72,12 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
     const bool in_frame = x < w;
     const bool full = xw + STRIP_PX <= w;
     const int nvec = full ? NV * 64 : (w - xw) * CH / 16;                    // 16-byte vectors of this strip row inside the frame
+    // strip halo: lane 0 fetches the 16 bytes that END at the strip's first byte (pixel xw-1 is in there), lane 63 the 16
+    // bytes that START after its last byte (pixel xw+1024).  One aligned dwordx4 per row for two lanes; nothing is
+    // done with it until it is used, so it does not force an early s_waitcnt in the middle of the row loads.
     const int hx = lane == 0 ? xw - 1 : xw + STRIP_PX;
     const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+    const ptrdiff_t hoff = lane == 0 ? (ptrdiff_t)xw * CH - 16 : (ptrdiff_t)(xw + STRIP_PX) * CH;   // byte offset in the row
 
     StateF2 st;
     st.clear();
@@ -83,27 +87,41 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
     constexpr int NROWS = R + 2;
     static_assert(NROWS % C == 0, "R + 2 must be a multiple of the chunk");
     constexpr int NCH = NROWS / C;
+
+    // ROLL = 1: rolling prefetch, C rows deep, at no register cost: the staging registers of strip row i are dead as
+    // soon as they have been written to the LDS slab, so the loads of row i + C are issued into the same registers
+    // right there, before row i is computed.  ROLL = 0: the C rows of a chunk are loaded together, then computed.
+    // Measured on MI355X (16384^2): ROLL = 0 is 7 % faster -- more rows in flight per wave make the row-strided
+    // HBM pattern worse, exactly as in the no-compute strip-copy probe (tools/ubench, "pattern").
+    uint4 v[C][NV];
+    uint4 hp[C];
+    auto issue_row = [&](int i, uint4 (&vr)[NV], uint4 &hr) {
+        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);   // always a readable row
+        const uint8_t *rowb = rgb + ((ptrdiff_t)yy * w) * CH;
+        const uint4 *rowp = reinterpret_cast<const uint4 *>(rowb + (size_t)xw * CH);
+        if (full) {                                   // wave-uniform: the whole strip row is inside the frame
+#pragma unroll
+            for (int k = 0; k < NV; ++k) vr[k] = load_stream(rowp + 64 * k + lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                vr[k] = make_uint4(0, 0, 0, 0);
+                if (64 * k + lane < nvec) vr[k] = load_stream(rowp + 64 * k + lane);
+            }
+        }
+        hr = make_uint4(0, 0, 0, 0);
+        if (hvalid) hr = *reinterpret_cast<const uint4 *>(rowb + hoff);
+    };
+    if (ROLL) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) issue_row(j, v[j], hp[j]);
+    }
+
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-        uint4 v[C][NV];
-        uint32_t hp[C][3];
+        if (!ROLL) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
-            const int yy = clamp_row(y0 - 1 + ch * C + j, rows, zero_top, zero_bot);   // always a readable row
-            const uint8_t *rowb = rgb + ((ptrdiff_t)yy * w) * CH;
-            const uint4 *rowp = reinterpret_cast<const uint4 *>(rowb + (size_t)xw * CH);
-            if (full) {                                   // wave-uniform: the whole strip row is inside the frame
-#pragma unroll
-                for (int k = 0; k < NV; ++k) v[j][k] = load_stream(rowp + 64 * k + lane);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    v[j][k] = make_uint4(0, 0, 0, 0);
-                    if (64 * k + lane < nvec) v[j][k] = load_stream(rowp + 64 * k + lane);
-                }
-            }
-            hp[j][0] = hp[j][1] = hp[j][2] = 0;
-            if (hvalid) { const uint8_t *h = rowb + (size_t)hx * CH; hp[j][0] = h[0]; hp[j][1] = h[1]; hp[j][2] = h[2]; }
+            for (int j = 0; j < C; ++j) issue_row(ch * C + j, v[j], hp[j]);
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -111,6 +129,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
             // de-interleave: the wave's row (lane-linear vectors) -> LDS -> 16 consecutive pixels per lane
 #pragma unroll
             for (int k = 0; k < NV; ++k) sw[64 * k + lane] = v[j][k];
+            const uint4 hq = hp[j];
+            if (ROLL && ch + 1 < NCH) issue_row(i + C, v[j], hp[j]);   // prefetch row i + C into the registers just freed
             __builtin_amdgcn_wave_barrier();     // same wave, DS ops execute in order: only a scheduling fence
             uint32_t wv[4 * NV];
 #pragma unroll
@@ -133,7 +153,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
                 }
                 G[m + 1] = luma_f2<MODE>(r2, g2, b2);
             }
-            const float hl = luma_f<MODE>(hp[j][0], hp[j][1], hp[j][2]);
+            // halo pixel bytes: lane 0 -> last pixel of the left chunk, lane 63 -> first pixel of the right chunk
+            const uint32_t hw = lane == 0 ? (CH == 3 ? (hq.w >> 8) : hq.w) : hq.x;      // R,G,B in bytes 0,1,2
+            const float hl = luma_f<MODE>(gh_byte(hw, 0), gh_byte(hw, 1), gh_byte(hw, 2));
             // strip halo: pixel x-1 is the left lane's pixel 15 (G[8].y), pixel x+16 the right lane's pixel 0 (G[1].x)
             // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element expression reads
             //  element 0 of the vector with this hipcc, which silently turned G[8].y into G[8].x)
@@ -231,20 +253,35 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
     static const bool use_tile = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
     if (!use_tile) {
-        constexpr int R = 32, C = 2;
+        static const int variant = [] { const char *e = getenv("GH_FUSED_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (width + span - 1) / span;
-        const long long nb = (long long)groups_x * ((rows + R - 1) / R);
-        GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        const unsigned g = (unsigned)nb;
         const unsigned b = stream_core::BLOCK;
-        if (channels == 3) {
-            if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 3, R, C><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);
-            else k_fused_stream<GH_MODE_IEEE, 3, R, C><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);
-        } else {
-            if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 4, R, C><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);
-            else k_fused_stream<GH_MODE_IEEE, 4, R, C><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);
+#define GH_FUSED_LAUNCH(R_, C_, RL_)                                                                                         \
+        do {                                                                                                              \
+            const long long nb = (long long)groups_x * ((rows + (R_) - 1) / (R_));                                         \
+            GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");                                                \
+            const unsigned g = (unsigned)nb;                                                                              \
+            if (channels == 3) {                                                                                          \
+                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);  \
+                else k_fused_stream<GH_MODE_IEEE, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);                     \
+            } else {                                                                                                      \
+                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);  \
+                else k_fused_stream<GH_MODE_IEEE, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);                     \
+            }                                                                                                             \
+        } while (0)
+        // strip height: taller strips re-read fewer halo rows (2 per strip) but a shard must still fill the 256 CUs
+        const long long bands16 = (rows + 15) / 16;
+        int pick = variant;
+        if (pick == 0) pick = (groups_x * ((bands16 + 3) / 4) >= 2048) ? 64 : ((groups_x * ((bands16 + 1) / 2) >= 1024) ? 32 : 16);
+        switch (pick) {
+        case 64: GH_FUSED_LAUNCH(64, 2, 1); break;
+        case 32: GH_FUSED_LAUNCH(32, 2, 1); break;
+        case 16: GH_FUSED_LAUNCH(16, 2, 1); break;
+        case 1: GH_FUSED_LAUNCH(32, 2, 0); break;      // tuning: chunked loads instead of the rolling prefetch
+        default: GH_FUSED_LAUNCH(32, 2, 1); break;
         }
+#undef GH_FUSED_LAUNCH
         GH_LAUNCH_CHECK();
         return GH_OK;
     }

@@ -802,6 +802,9 @@ static void bench_pattern31(int W, int H)
 #define P31(R_, C_, NT_, WPB_) vs.push_back({"strip 3R:1W R" #R_ " C" #C_ " nt" #NT_ " waves/blk" #WPB_, [=] { const int g = (W + 1024 * WPB_ - 1) / (1024 * WPB_); k_pat31<R_, C_, NT_, WPB_><<<g * ((H + R_ - 1) / R_), 64 * WPB_>>>(rgb, out, W, H, g); }, 4.0 * npix})
     P31(32, 2, 1, 4); P31(32, 4, 1, 4); P31(16, 2, 1, 4); P31(64, 2, 1, 4); P31(8, 2, 1, 4); P31(32, 2, 0, 4); P31(32, 1, 1, 4);
     P31(32, 2, 1, 16); P31(16, 2, 1, 16); P31(8, 2, 1, 16); P31(64, 2, 1, 16); P31(32, 2, 1, 8); P31(32, 2, 1, 2); P31(32, 2, 1, 1); P31(4, 2, 1, 16); P31(2, 2, 1, 16); P31(1, 1, 1, 16); P31(1, 1, 1, 4);
+    // occupancy sensitivity: same strip copy, workgroups per CU limited by a dummy dynamic-LDS allocation
+#define P31L(R_, C_, KB_) vs.push_back({"strip 3R:1W R" #R_ " C" #C_ " nt1 waves/blk4 LDS" #KB_ "KiB", [=] { const int g = (W + 4095) / 4096; k_pat31<R_, C_, 1, 4><<<g * ((H + R_ - 1) / R_), 256, KB_ * 1024>>>(rgb, out, W, H, g); }, 4.0 * npix})
+    P31L(32, 2, 20); P31L(32, 2, 26); P31L(32, 2, 32); P31L(32, 2, 40); P31L(32, 2, 53); P31L(32, 2, 80); P31L(32, 4, 53); P31L(32, 6, 53); P31L(32, 4, 80); P31L(32, 8, 80);
     run_table("access-pattern ceiling: 3R+1W (fused shape)", vs, (double)npix);
     CK(hipFree(rgb)); CK(hipFree(out));
 }
