@@ -6,15 +6,18 @@ synthetic 16384 x 16384 frame (BASELINE.json configs[2]; row-sharded over N GPUs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one frame that is already resident in HBM:
-    gray_rgb8_to_plane (3 R + 1 W B/px)  ->  [1-row luma halo exchange over RCCL when N > 1]
-    ->  sobel3x3_u8 (1 R + 1 W B/px)                                   (--pipeline split, default)
-or the single fused kernel RGB -> edge (3 R + 1 W B/px, luma never leaves the chip; --pipeline fused).
-Every kernel is the hand-written gfx950 code in libgrayhip.so, called through its C ABI; torch is
-only the allocator, the stream provider and the process group.
+    --pipeline fused (default): ONE kernel, RGB -> luma -> Sobel edge plane, 3 R + 1 W bytes per pixel
+                                (the luma plane never leaves the chip);
+    --pipeline split          : gray_rgb8_to_plane (3 R + 1 W B/px) then sobel3x3_u8 (1 R + 1 W B/px).
+With N > 1 the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with
+each neighbour over RCCL (torch.distributed P2P): an RGB row for the fused pipeline, a luma row for the
+split one -- overlapped with the interior rows, which do not depend on it.
+Every kernel is the hand-written gfx950 code in libgrayhip.so, called through its C ABI; torch is only
+the allocator, the stream provider and the process group.
 
-Prints ONE JSON line on rank 0: Mpixels/s over the whole job, the HBM roofline fraction of the
-dominant kernel (HIP-event timed inside the timed region), and the reference's OpenMP CPU path
-timed on this box's host cores (a reported baseline, not the target).
+Prints ONE JSON line on rank 0: Mpixels/s over the whole job, the HBM roofline fraction of the dominant
+kernel (HIP-event timed inside the timed region), a per-kernel table, and the reference's OpenMP CPU
+path timed on this box's host cores (a reported baseline, not the target).
 """
 from __future__ import annotations
 
@@ -29,11 +32,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6600 GB/s is the measured copy ceiling
 ALGO_BYTES_PER_PX = {          # each image byte counted once
-    "gray_rgb8_to_plane": 4,   # 3 R + 1 W
-    "sobel3x3_u8": 2,          # 1 R + 1 W
     "gray_sobel_fused_rgb8": 4,  # 3 R + 1 W
+    "gray_rgb8_to_plane": 4,     # 3 R + 1 W
+    "sobel3x3_u8": 2,            # 1 R + 1 W
+    "gray_inplace_rgb8": 6,      # 3 R + 3 W (the reference ABI's in-place form)
 }
 
 
@@ -44,23 +48,25 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=16384)
     ap.add_argument("--height", type=int, default=16384)
-    ap.add_argument("--pipeline", choices=["split", "fused"], default=os.environ.get("GH_BENCH_PIPELINE", "split"))
+    ap.add_argument("--pipeline", choices=["fused", "split"], default=os.environ.get("GH_BENCH_PIPELINE", "fused"))
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="strong: the 16384^2 frame is row-sharded over N GPUs; weak: every GPU gets 16384 rows")
+                    help="strong: the 16384^2 frame is row-sharded over N GPUs; weak: every GPU gets `height` rows")
     ap.add_argument("--mode", choices=["ieee", "fma"], default="ieee")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the halo exchange with interior rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel measurements after the timed region")
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity spot check against the oracle")
     return ap.parse_args()
 
 
-def cpu_baseline(width: int, sample_rows: int, seed_frame=None) -> dict:
-    """The reference's OpenMP CPU path on this box's host cores, kernel-only timing
-    (clock around the calls like monolithic/src/main.c:30-38), on a bounded sample: the first
-    `sample_rows` rows of the frame.  Uses the reference's own sources compiled in place
-    (oracle/_ref/libref_ieee.so, kind "reference") when that prebuilt file travelled with the repo,
-    otherwise this repo's C restatement (oracle/liboracle.so, kind "port")."""
+def cpu_baseline(width: int, sample_rows: int) -> dict:
+    """The reference's OpenMP CPU path on this box's host cores, kernel-only timing (clock around the calls like
+    monolithic/src/main.c:30-38), on a bounded sample: the first `sample_rows` rows of the frame.  Uses the
+    reference's own sources compiled in place (oracle/_ref/libref_ieee.so, kind "reference") when that prebuilt
+    file travelled with the repo, otherwise this repo's C restatement (oracle/liboracle.so, kind "port")."""
+    import ctypes as C
+
     import numpy as np
     from oracle import pyoracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -69,10 +75,9 @@ def cpu_baseline(width: int, sample_rows: int, seed_frame=None) -> dict:
     npix = width * sample_rows
     img0 = O.frame_rand(width, sample_rows, 3, seed=1)
     kind = "reference" if O.have_ref("ieee") else "port"
+    u8p = C.POINTER(C.c_uint8)
     if kind == "reference":
         ref = O.RefLib("ieee")
-        import ctypes as C
-        u8p = C.POINTER(C.c_uint8)
 
         def run_gray(buf):
             ref.L.convert_to_grayscale(buf.ctypes.data_as(u8p), width, sample_rows, 3)
@@ -81,8 +86,6 @@ def cpu_baseline(width: int, sample_rows: int, seed_frame=None) -> dict:
             ref.L.sobel_edge(src.ctypes.data_as(u8p), dst.ctypes.data_as(u8p), width, sample_rows)
     else:
         L = O.lib()
-        import ctypes as C
-        u8p = C.POINTER(C.c_uint8)
 
         def run_gray(buf):
             L.orc_gray_inplace(buf.ctypes.data_as(u8p), width, sample_rows, 3, O.MODE_IEEE)
@@ -148,49 +151,41 @@ def main() -> int:
     y0, y1 = sharding.row_partition(H_total, world)[rank]
     rows = y1 - y0
     geom = sharding.ShardGeometry(rank, world, W, y0, y1)
+    fused = args.pipeline == "fused"
+    overlap = not args.no_overlap
+    backend = sharding.HipBackend(mode)
 
     # synthetic frame shard, resident in HBM before the timed region
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    fused = args.pipeline == "fused"
     if fused:
-        # RGB halo rows live next to the shard: zero-communication variant (halo luma recomputed)
-        rgb_buf = torch.randint(0, 256, (rows + 2, W, 3), dtype=torch.uint8, device=device, generator=gen)
-        rgb = rgb_buf[1:rows + 1]
-        edge = torch.empty((rows, W), dtype=torch.uint8, device=device)
-        if world > 1:   # make the halo rows the neighbours' real rows once, outside the timed region
-            ops = []
-            if rank > 0:
-                ops += [dist.P2POp(dist.isend, rgb_buf[1], rank - 1), dist.P2POp(dist.irecv, rgb_buf[0], rank - 1)]
-            if rank < world - 1:
-                ops += [dist.P2POp(dist.isend, rgb_buf[rows], rank + 1), dist.P2POp(dist.irecv, rgb_buf[rows + 1], rank + 1)]
-            for wk in dist.batch_isend_irecv(ops):
-                wk.wait()
-        runner = None
+        runner = sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap)
+        runner.shard.copy_(torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen))
+        rgb = runner.shard
     else:
+        runner = sharding.ShardedGraySobel(geom, backend, device, overlap=overlap)
         rgb = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
-        runner = sharding.ShardedGraySobel(geom, sharding.HipBackend(mode), device, overlap=not args.no_overlap)
-        edge = runner.edge
+    edge = runner.edge
 
     stream = torch.cuda.current_stream()
-    n_ev = 3 if (not fused and world == 1) else 2
+    single = world == 1
+    n_ev = 3 if (single and not fused) else 2
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
 
     def step(ev=None):
+        if ev:
+            ev[0].record(stream)
         if fused:
-            if ev: ev[0].record(stream)
-            api.gray_sobel_fused_rows(rgb_buf, edge, rows, mode, geom.top_is_border, geom.bottom_is_border)
-            if ev: ev[1].record(stream)
-        elif world == 1:
-            if ev: ev[0].record(stream)
+            runner.step()
+        elif single:
             api.gray_to_plane(rgb, mode, out=runner.luma[1:rows + 1])
-            if ev: ev[1].record(stream)
+            if ev:
+                ev[1].record(stream)
             api.sobel_rows(runner.luma, edge, rows, True, True)
-            if ev: ev[2].record(stream)
         else:
-            if ev: ev[0].record(stream)
             runner.step(rgb)
-            if ev: ev[1].record(stream)
+        if ev:
+            ev[-1].record(stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -212,15 +207,14 @@ def main() -> int:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # per-kernel durations from the HIP events recorded inside the timed region
     px_rank = rows * W
-    kernels = {}
-    if fused:
-        kernels["gray_sobel_fused_rgb8"] = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    elif world == 1:
-        kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-        kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
     step_ms_events = sum(e[0].elapsed_time(e[-1]) for e in events) / args.steps
+    timed_kernels = {}
+    if single and fused:
+        timed_kernels["gray_sobel_fused_rgb8"] = step_ms_events
+    elif single:
+        timed_kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+        timed_kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
 
     # parity spot check of what was just timed (checker only; not in the timed region)
     check = "skipped"
@@ -229,43 +223,68 @@ def main() -> int:
             import numpy as np
             from oracle import pyoracle as O
             r = min(rows, 96)
-            src = (rgb_buf[0:r + 2] if fused else rgb[0:r + 1]).cpu().numpy()
-            if fused:
-                lum = O.gray_to_plane(np.ascontiguousarray(src[1:]), mode)       # rows 0..r of the shard
-            else:
-                lum = O.gray_to_plane(src, mode)
-            want = O.sobel(lum)[: r - 1]
+            src = rgb[0:r + 1].cpu().numpy()
+            want = O.sobel(O.gray_to_plane(src, mode))[: r - 1]
             got = edge[: r - 1].cpu().numpy()
             check = "ok" if np.array_equal(got[1:], want[1:]) and not got[0].any() else "MISMATCH"
-        except Exception as exc:  # the checker is optional on the GPU box; never hide a mismatch
+        except Exception as exc:  # the checker is optional on the GPU box; a mismatch is never hidden
             check = f"unavailable ({type(exc).__name__})"
         if check == "MISMATCH":
             print("bench.py: parity spot check FAILED", file=sys.stderr)
             return 3
 
+    # per-kernel table (outside the timed region): every kernel of the hot path on this rank's shard
+    def time_kernel(fn, reps=30):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(reps):
+            fn()
+        b.record(stream)
+        b.synchronize()
+        return a.elapsed_time(b) / reps
+
+    kern_ms = dict(timed_kernels)
+    if single and not args.no_kernel_table and rank == 0:
+        luma = torch.empty((rows + 2, W), dtype=torch.uint8, device=device)
+        tmp_edge = torch.empty((rows, W), dtype=torch.uint8, device=device)
+        if "gray_rgb8_to_plane" not in kern_ms:
+            kern_ms["gray_rgb8_to_plane"] = time_kernel(lambda: api.gray_to_plane(rgb, mode, out=luma[1:rows + 1]))
+        else:
+            api.gray_to_plane(rgb, mode, out=luma[1:rows + 1])
+        if "sobel3x3_u8" not in kern_ms:
+            kern_ms["sobel3x3_u8"] = time_kernel(lambda: api.sobel_rows(luma, tmp_edge, rows, True, True))
+        if "gray_sobel_fused_rgb8" not in kern_ms:
+            kern_ms["gray_sobel_fused_rgb8"] = time_kernel(lambda: api.gray_sobel_fused(rgb, mode, out=tmp_edge))
+        scratch = rgb.clone()
+        kern_ms["gray_inplace_rgb8"] = time_kernel(lambda: api.gray_inplace(scratch, mode))
+        del luma, tmp_edge, scratch
+
     if rank == 0:
         total_px = W * H_total * args.steps
         value = total_px / elapsed / 1e6
-        dom = max(kernels, key=kernels.get) if kernels else None
-        roofline = None
         kern_table = {}
-        for name, ms in kernels.items():
+        for name, ms in kern_ms.items():
             gbs = ALGO_BYTES_PER_PX[name] * px_rank / (ms * 1e-3) / 1e9
             kern_table[name] = {"ms": round(ms, 4), "algo_bytes": ALGO_BYTES_PER_PX[name] * px_rank,
                                 "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
-                                "Mpixels/s": round(px_rank / (ms * 1e-3) / 1e6, 1)}
-        if dom:
+                                "Mpixels/s": round(px_rank / (ms * 1e-3) / 1e6, 1),
+                                "in_timed_region": name in timed_kernels}
+        if timed_kernels:
+            dom = max(timed_kernels, key=timed_kernels.get)
             a = kern_table[dom]["GB/s"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
                         "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"]}
         else:
-            # N > 1: the step interleaves kernels with the RCCL exchange; report the step's aggregate traffic rate
-            bpp = 6
+            # N > 1: the step interleaves kernels with the RCCL exchange; report the step's aggregate traffic rate per rank
+            bpp = 4 if fused else 6
             a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "gray_rgb8_to_plane+sobel3x3_u8 (per rank, incl. halo exchange)",
-                        "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                        "traffic": None}
+            roofline = {"bound": "hbm", "kernel": ("gray_sobel_fused_rgb8" if fused else "gray_rgb8_to_plane+sobel3x3_u8")
+                        + " (per rank, incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None}
+        halo = "an RGB row (fused kernel recomputes halo luma)" if fused else "a luma row"
         out = {
             "metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel",
             "value": round(value, 1),
@@ -280,11 +299,12 @@ def main() -> int:
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H_total} RGB8 frame resident in HBM -> luma plane -> 3x3 Sobel edge plane "
+                "workload": f"{W}x{H_total} RGB8 frame resident in HBM -> luma -> 3x3 Sobel edge plane "
                             f"(BASELINE configs[{2 if world == 1 else 3}]), pipeline={args.pipeline}, mode={args.mode}",
                 "width": W, "height": H_total, "rows_per_gpu": rows,
-                "parallelism": "single GPU" if world == 1 else f"row-sharded x{world}, 1-row luma halo via RCCL send/recv"
-                               + ("" if args.no_overlap else ", overlapped with interior rows"),
+                "parallelism": "single GPU" if world == 1 else
+                               f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv"
+                               + ("" if args.no_overlap else ", overlapped with the interior rows"),
             },
             "roofline": roofline,
             "kernels": kern_table,

@@ -48,6 +48,9 @@ class HipBackend:
     def sobel_rows(self, buf, out, rows, top_is_border, bottom_is_border):
         return self.api.sobel_rows(buf, out, rows, top_is_border, bottom_is_border)
 
+    def fused_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        return self.api.gray_sobel_fused_rows(buf, out, rows, self.mode, top_is_border, bottom_is_border)
+
     def sum_rgb(self, rgb):
         return self.api.sum_rgb_dev(rgb)
 
@@ -126,6 +129,64 @@ class ShardedGraySobel:
             for wk in works:
                 wk.wait()
             self.backend.sobel_rows(self.luma, self.edge, rows, g.top_is_border, g.bottom_is_border)
+        return self.edge
+
+
+class ShardedFusedGraySobel:
+    """One rank's share of the FUSED `RGB -> luma -> Sobel` kernel on a row-sharded frame.
+
+    The halo exchanged per frame is one RGB row per neighbour (width * channels bytes) instead of one luma row:
+    the fused kernel recomputes the halo luma, so the luma plane never exists in HBM.  `rgb` is
+    (rows+2, width, channels): rows 1..rows hold the shard (write new frames there), rows 0 / rows+1 receive the
+    neighbours' edge rows.  step() enqueues exchange + kernels asynchronously and returns `edge`.
+    """
+
+    def __init__(self, geom: ShardGeometry, backend, device, channels: int = 3, group=None, overlap: bool = True):
+        import torch
+        self.g = geom
+        self.backend = backend
+        self.group = group
+        self.overlap = overlap
+        self.rgb = torch.zeros((geom.rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
+        self.edge = torch.empty((geom.rows, geom.width), dtype=torch.uint8, device=device)
+
+    @property
+    def shard(self):
+        return self.rgb[1:self.g.rows + 1]
+
+    def _exchange_ops(self):
+        import torch.distributed as dist
+        g, buf = self.g, self.rgb
+        ops = []
+        if not g.top_is_border:
+            ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
+        if not g.bottom_is_border:
+            ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
+        return ops
+
+    def step(self):
+        import torch.distributed as dist
+        g = self.g
+        rows = g.rows
+        if rows == 0:
+            return self.edge
+        if g.world == 1:
+            self.backend.fused_rows(self.rgb, self.edge, rows, True, True)
+            return self.edge
+        ops = self._exchange_ops()
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if self.overlap and rows >= 3:
+            self.backend.fused_rows(self.rgb[1:rows + 1], self.edge[1:rows - 1], rows - 2, False, False)
+            for wk in works:
+                wk.wait()
+            self.backend.fused_rows(self.rgb[0:3], self.edge[0:1], 1, g.top_is_border, False)
+            self.backend.fused_rows(self.rgb[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+        else:
+            for wk in works:
+                wk.wait()
+            self.backend.fused_rows(self.rgb, self.edge, rows, g.top_is_border, g.bottom_is_border)
         return self.edge
 
 

@@ -45,6 +45,10 @@ class OracleBackend:
         out.copy_(torch.from_numpy(e))
         return out
 
+    def fused_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        luma = torch.from_numpy(self.O.gray_to_plane(buf.numpy(), self.mode))
+        return self.sobel_rows(luma, out, rows, top_is_border, bottom_is_border)
+
     def sum_rgb(self, rgb):
         return self.O.sum_rgb(rgb.numpy())
 
@@ -78,9 +82,13 @@ def _worker(rank, world, port, w, h, overlap, seed, q):
         shard = torch.from_numpy(np.ascontiguousarray(frame[y0:y1]))
         edge = runner.step(shard).numpy().copy()
         edge2 = runner.step(shard).numpy().copy()       # second step reuses the buffers
+        fused = sharding.ShardedFusedGraySobel(geom, OracleBackend(0), torch.device("cpu"), overlap=overlap)
+        fused.shard.copy_(shard)
+        edge3 = fused.step().numpy().copy()
         sums = sharding.allreduce_channel_sums(OracleBackend(0).sum_rgb(shard) if y1 > y0 else [0, 0, 0], torch.device("cpu"))
         want = O.sobel(O.gray_to_plane(frame, 0))
-        ok = np.array_equal(edge, want[y0:y1]) and np.array_equal(edge2, edge) and sums == O.sum_rgb(frame)
+        ok = (np.array_equal(edge, want[y0:y1]) and np.array_equal(edge2, edge) and np.array_equal(edge3, edge)
+              and sums == O.sum_rgb(frame))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
