@@ -37,7 +37,11 @@ $(LIB): $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
 CLI_COMMON := $(CSRC)/cli/image_io.cpp $(CSRC)/cli/jpeg_decode.cpp
-cli: bin/grayscale bin/grayscale_sobel
+cli: bin/grayscale bin/grayscale_sobel bin/gh_imgtool
+
+bin/gh_imgtool: $(CSRC)/cli/imgtool.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h
+	@mkdir -p bin
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/imgtool.cpp $(CLI_COMMON) -lz -o $@
 
 bin/grayscale: $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h $(LIB)
 	@mkdir -p bin

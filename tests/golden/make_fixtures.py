@@ -101,6 +101,23 @@ def main() -> None:
         res["rgba_alpha"] = np.ascontiguousarray(rgba[..., 3])
         del res["rgb"], res["rgba"]      # rgb == test_jpg_crop.npz:rgb ; rgba = rgb + rgba_alpha
         np.savez_compressed(os.path.join(ROOT, "tests/golden/cli_crop.npz"), **res)
+        # full-frame digests for the CLI file-level tests (tests/golden/test.jpg is a copy of the reference's images/test.jpg)
+        import json
+        full = {"decoded_rgb_sha256": digest,
+                "gray_ieee_rgb_sha256": hashlib.sha256(g_ieee.data).hexdigest(),      # == decoded images/test_gray.png
+                "gray_fma_rgb_sha256": hashlib.sha256(g_fma.data).hexdigest()}
+        for exe, tag in (("grayscale_ieee", "cli_gray"), ("grayscale_sobel_ieee", "cli_sobel")):
+            for passes in (1, 2):
+                dst = os.path.join(tmp, "full.png")
+                subprocess.run([os.path.join(refdir, exe), f"{REF}/images/test.jpg", dst, str(passes)], check=True, capture_output=True)
+                full[f"{tag}_p{passes}_rgb_sha256"] = hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(dst))).data).hexdigest()
+        assert full["cli_gray_p1_rgb_sha256"] == full["gray_ieee_rgb_sha256"]
+        for name in ("half_of_a_mega_photo.jpg", "more_than_one_mega_photo.jpg"):
+            raw2 = os.path.join(tmp, "o.raw")
+            subprocess.run([os.path.join(refdir, "stb_decode"), f"{REF}/images/{name}", raw2], check=True, capture_output=True)
+            full[f"decoded_{name}_sha256"] = hashlib.sha256(open(raw2, "rb").read()).hexdigest()
+        with open(os.path.join(ROOT, "tests/golden/test_jpg_full.json"), "w") as f:
+            json.dump(full, f, indent=1)
         b = res["sobel_rgb_p1_c0"]
         print("fixtures written; sobel p1 border all zero:",
               bool((b[0] == 0).all() and (b[-1] == 0).all() and (b[:, 0] == 0).all() and (b[:, -1] == 0).all()))

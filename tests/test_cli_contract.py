@@ -1,0 +1,117 @@
+"""The drop-in CLI contract of the reference's drivers (monolithic/src/main.c, main_with_sobel.c):
+    bin/grayscale <input_img> <output_img.png> [passes]
+same argv handling, stdout line, stderr texts and exit codes; what the reference's bench script and the Flask /
+RabbitMQ wrappers rely on.  Error paths run anywhere; full runs need the GPU."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN, ROOT
+
+GRAY = os.path.join(ROOT, "bin", "grayscale")
+SOBEL = os.path.join(ROOT, "bin", "grayscale_sobel")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.access(GRAY, os.X_OK) and os.access(SOBEL, os.X_OK)):
+        subprocess.run(["make", "-C", ROOT, "cli"], check=True, capture_output=True)
+
+
+def run(exe, *args, env=None):
+    e = dict(os.environ)
+    e.pop("GRAYHIP_VERBOSE", None)
+    if env:
+        e.update(env)
+    return subprocess.run([exe, *map(str, args)], capture_output=True, text=True, env=e)
+
+
+@pytest.mark.parametrize("exe", [GRAY, SOBEL])
+def test_usage_and_load_errors(exe, tmp_path):
+    p = run(exe)
+    assert p.returncode == 1 and p.stdout == ""
+    assert p.stderr == f"Uso: {exe} <input_img> <output_img.png> [passaggi_kernel]\n"        # main.c:16
+    p = run(exe, "only_one_arg")
+    assert p.returncode == 1 and p.stderr.startswith("Uso: ")
+    missing = tmp_path / "nope.png"
+    p = run(exe, missing, tmp_path / "o.png")
+    assert p.returncode == 1 and p.stdout == ""
+    if exe == GRAY:
+        assert p.stderr == "Errore caricando immagine\n"                                     # main.c:23
+    else:
+        assert p.stderr == f'Errore caricando immagine "{missing}"\n'                        # main_with_sobel.c:30-31
+    junk = tmp_path / "junk.jpg"
+    junk.write_bytes(b"definitely not an image")
+    assert run(exe, junk, tmp_path / "o.png").returncode == 1
+
+
+@pytest.mark.gpu
+def test_gray_cli_reproduces_the_reference_golden_file(tmp_path):
+    """bin/grayscale images/test.jpg out.png -> the pixels of the reference's committed images/test_gray.png."""
+    full = json.load(open(os.path.join(GOLDEN, "test_jpg_full.json")))
+    out = tmp_path / "out.png"
+    p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out)
+    assert p.returncode == 0 and p.stderr == ""                       # stderr must stay empty (bench script parses it)
+    assert re.fullmatch(r"Compute kernel ×1: \d+\.\d{4} s\n", p.stdout)
+    img = np.asarray(Image.open(out))
+    assert img.shape == (1080, 1920, 3)
+    assert hashlib.sha256(np.ascontiguousarray(img).data).hexdigest() == full["gray_ieee_rgb_sha256"]
+    p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out, 2)
+    assert p.returncode == 0 and p.stdout.startswith("Compute kernel ×2: ")
+    assert hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest() == full["cli_gray_p2_rgb_sha256"]
+    p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out, env={"GRAYHIP_MODE": "fma"})
+    assert hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest() == full["gray_fma_rgb_sha256"]
+
+
+@pytest.mark.gpu
+def test_sobel_cli_matches_reference_cli(tmp_path):
+    full = json.load(open(os.path.join(GOLDEN, "test_jpg_full.json")))
+    out = tmp_path / "out.png"
+    for passes in (1, 2):
+        p = run(SOBEL, os.path.join(GOLDEN, "test.jpg"), out, passes)
+        assert p.returncode == 0 and p.stderr == ""
+        assert re.fullmatch(rf"Compute kernel \(grayscale \+ sobel\) ×{passes}: \d+\.\d{{4}} s\n", p.stdout)
+        got = hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest()
+        assert got == full[f"cli_sobel_p{passes}_rgb_sha256"], passes
+
+
+@pytest.mark.gpu
+def test_passes_parsing_rgba_and_save_failures(tmp_path, jpg_crop, cli_crop):
+    rgb = jpg_crop["rgb"]
+    src = tmp_path / "crop.png"
+    Image.fromarray(rgb).save(src)
+    out = tmp_path / "o.png"
+    for arg, expect in (("0", 1), ("abc", 1), ("-5", 1), ("3", 3)):              # atoi, <1 -> 1  (main.c:27-28)
+        p = run(GRAY, src, out, arg)
+        assert p.returncode == 0 and p.stdout.startswith(f"Compute kernel ×{expect}: ")
+    assert np.array_equal(np.asarray(Image.open(out))[..., 0], cli_crop["gray_rgb_p2_c0"])   # passes=3 == passes=2
+    rgba = np.dstack([rgb, cli_crop["rgba_alpha"]])
+    srca = tmp_path / "crop_rgba.png"
+    Image.fromarray(rgba, "RGBA").save(srca)
+    assert run(SOBEL, srca, out, 2).returncode == 0
+    got = np.asarray(Image.open(out))
+    assert got.shape == rgba.shape                                               # same channel count as the input
+    assert np.array_equal(got[..., 0], cli_crop["sobel_rgba_p2_c0"]) and np.array_equal(got[..., 3], rgba[..., 3])
+    bad = tmp_path / "no_such_dir" / "o.png"
+    p = run(GRAY, src, bad)
+    assert p.returncode == 1 and p.stderr == "Errore nel salvataggio\n" and p.stdout.startswith("Compute kernel")
+    p = run(SOBEL, src, bad)
+    assert p.returncode == 0 and p.stderr == f'Errore nel salvataggio di "{bad}"\n'       # exit code stays 0 (main_with_sobel.c:83-91)
+
+
+@pytest.mark.gpu
+def test_flask_style_caller(tmp_path, jpg_crop):
+    """What microservices/grayscale/app.py:24-38 does: exec [binary, in, out(, passes)], needs rc 0 and out.png."""
+    src = tmp_path / "upload.png"
+    Image.fromarray(jpg_crop["rgb"]).save(src)
+    out = tmp_path / "out.png"
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    result = subprocess.run([GRAY, str(src), str(out), "2"], capture_output=True, env=env)
+    assert result.returncode == 0 and out.exists()
+    assert np.array_equal(np.asarray(Image.open(out))[..., 0], np.asarray(Image.open(out))[..., 2])

@@ -1,0 +1,145 @@
+"""The drop-in CLIs' image codec (csrc/cli/image_io.cpp, jpeg_decode.cpp), exercised without a GPU through
+bin/gh_imgtool.  The reference decodes with the stb_image.h it vendors (monolithic/src/main.c:21); its JPEG
+output differs from libjpeg/PIL by up to +-3, so the checks here are against digests of the reference's own
+decoder output (tests/golden/test_jpg_full.json, written by make_fixtures.py) and, in the build container,
+against that decoder compiled in place (oracle/_ref/stb_decode)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN, ROOT
+
+TOOL = os.path.join(ROOT, "bin", "gh_imgtool")
+REF_IMAGES = "/root/reference/images"
+STB = os.path.join(ROOT, "oracle", "_ref", "stb_decode")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.access(TOOL, os.X_OK):
+        subprocess.run(["make", "-C", ROOT, "bin/gh_imgtool"], check=True, capture_output=True)
+
+
+def decode(path, tmp_path):
+    raw = tmp_path / "d.raw"
+    p = subprocess.run([TOOL, "decode", str(path), str(raw)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    w, h, c = map(int, p.stdout.split())
+    return np.fromfile(raw, dtype=np.uint8).reshape(h, w, c)
+
+
+def encode(arr, path, tmp_path):
+    h, w = arr.shape[:2]
+    c = 1 if arr.ndim == 2 else arr.shape[2]
+    raw = tmp_path / "e.raw"
+    np.ascontiguousarray(arr).tofile(raw)
+    p = subprocess.run([TOOL, "encode", str(w), str(h), str(c), str(raw), str(path)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_jpeg_matches_the_reference_decoder_digest(tmp_path):
+    full = json.load(open(os.path.join(GOLDEN, "test_jpg_full.json")))
+    img = decode(os.path.join(GOLDEN, "test.jpg"), tmp_path)
+    assert img.shape == (1080, 1920, 3)
+    assert hashlib.sha256(img.data).hexdigest() == full["decoded_rgb_sha256"]
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_IMAGES) and os.access(STB, os.X_OK)), reason="reference tree only in the build container")
+@pytest.mark.parametrize("name", ["test.jpg", "half_of_a_mega_photo.jpg", "more_than_one_mega_photo.jpg", "test_gray.png"])
+def test_decoder_equals_reference_stb(tmp_path, name):
+    """baseline 4:4:4, progressive 4:2:0 with odd width, and an RGB PNG: pixel-identical to the reference's decoder."""
+    mine = decode(os.path.join(REF_IMAGES, name), tmp_path)
+    raw = tmp_path / "s.raw"
+    out = subprocess.run([STB, os.path.join(REF_IMAGES, name), str(raw)], check=True, capture_output=True, text=True).stdout.split()
+    w, h, c = map(int, out)
+    theirs = np.fromfile(raw, dtype=np.uint8).reshape(h, w, c)
+    assert mine.shape == theirs.shape and np.array_equal(mine, theirs)
+
+
+@pytest.mark.parametrize("w,h,c", [(1, 1, 1), (7, 3, 2), (53, 37, 3), (64, 64, 4), (300, 2, 3), (2, 300, 1)])
+def test_png_encode_roundtrip(tmp_path, w, h, c):
+    rng = np.random.RandomState(w * 100 + h + c)
+    arr = rng.randint(0, 256, size=(h, w, c) if c > 1 else (h, w), dtype=np.uint8)
+    if c >= 3:   # some smooth structure so every filter type gets picked
+        arr[: h // 2] = (np.add.outer(np.arange(h // 2), np.arange(w))[..., None] % 256).astype(np.uint8)
+    path = tmp_path / "o.png"
+    encode(arr, path, tmp_path)
+    back = np.asarray(Image.open(path))
+    assert back.shape == arr.shape and np.array_equal(back, arr)           # PIL reads what we wrote
+    mine = decode(path, tmp_path)
+    assert np.array_equal(mine.reshape(arr.shape), arr)                    # and so do we
+
+
+def test_png_decode_variants(tmp_path):
+    rng = np.random.RandomState(5)
+    rgb = rng.randint(0, 256, size=(33, 47, 3), dtype=np.uint8)
+    # interlaced RGB / RGBA / grey / grey+alpha / palette (+tRNS) / 16-bit / low bit depths
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    assert np.array_equal(decode(tmp_path / "a.png", tmp_path), rgb)
+    rgba = np.dstack([rgb, rng.randint(0, 256, size=(33, 47), dtype=np.uint8)])
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "b.png")
+    assert np.array_equal(decode(tmp_path / "b.png", tmp_path), rgba)
+    grey = rgb[..., 0]
+    Image.fromarray(grey, "L").save(tmp_path / "c.png")
+    assert np.array_equal(decode(tmp_path / "c.png", tmp_path)[..., 0], grey)
+    la = np.dstack([grey, rgb[..., 1]])
+    Image.fromarray(la, "LA").save(tmp_path / "d.png")
+    assert np.array_equal(decode(tmp_path / "d.png", tmp_path), la)
+    pal = Image.fromarray(rgb).quantize(colors=37)
+    pal.save(tmp_path / "e.png")
+    assert np.array_equal(decode(tmp_path / "e.png", tmp_path), np.asarray(pal.convert("RGB")))
+    one = Image.fromarray((grey > 127).astype(np.uint8) * 255, "L").convert("1")
+    one.save(tmp_path / "f.png")
+    assert np.array_equal(decode(tmp_path / "f.png", tmp_path)[..., 0], np.asarray(one.convert("L")))
+    g16 = (rng.randint(0, 65536, size=(9, 11)).astype(np.uint16))
+    Image.fromarray(g16, "I;16").save(tmp_path / "g.png")
+    assert np.array_equal(decode(tmp_path / "g.png", tmp_path)[..., 0], (g16 >> 8).astype(np.uint8))   # stb: high byte
+
+
+def _adam7_png(arr: np.ndarray) -> bytes:
+    """Minimal Adam7-interlaced 8-bit PNG writer (filter 0 everywhere) -- PIL cannot write interlaced files."""
+    import struct
+    import zlib
+    h, w = arr.shape[:2]
+    c = 1 if arr.ndim == 2 else arr.shape[2]
+    a = arr.reshape(h, w, c)
+    xs, ys, dx, dy = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+    raw = b""
+    for p in range(7):
+        sub = a[ys[p]::dy[p], xs[p]::dx[p]]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for row in sub:
+            raw += b"\x00" + row.tobytes()
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 1))
+            + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("w,h,c", [(1, 1, 3), (3, 2, 3), (8, 8, 1), (13, 21, 4), (47, 33, 3)])
+def test_png_adam7_interlaced(tmp_path, w, h, c):
+    rng = np.random.RandomState(w + 10 * h)
+    arr = rng.randint(0, 256, size=(h, w, c), dtype=np.uint8)
+    (tmp_path / "i.png").write_bytes(_adam7_png(arr))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "i.png")).reshape(h, w, c), arr)   # the file itself is valid
+    assert np.array_equal(decode(tmp_path / "i.png", tmp_path), arr)
+
+
+def test_pnm_and_garbage(tmp_path):
+    rng = np.random.RandomState(9)
+    rgb = rng.randint(0, 256, size=(5, 6, 3), dtype=np.uint8)
+    (tmp_path / "a.ppm").write_bytes(b"P6\n# comment\n6 5\n255\n" + rgb.tobytes())
+    assert np.array_equal(decode(tmp_path / "a.ppm", tmp_path), rgb)
+    (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really a jpeg")
+    p = subprocess.run([TOOL, "decode", str(tmp_path / "bad.jpg"), str(tmp_path / "x.raw")], capture_output=True)
+    assert p.returncode == 1
+    (tmp_path / "junk.bin").write_bytes(os.urandom(64))
+    assert subprocess.run([TOOL, "decode", str(tmp_path / "junk.bin"), str(tmp_path / "x.raw")], capture_output=True).returncode == 1

@@ -370,5 +370,6 @@ int main(int argc, char **argv)
     if (what == "sc" || what == "all") bench_streamc(W, H);
     if (what == "pattern" || what == "all") bench_pattern(W, H);
     if (what == "pattern31" || what == "all") bench_pattern31(W, H);
+    if (what == "pitch") bench_pitch(W, H);
     return 0;
 }

@@ -760,6 +760,35 @@ __global__ __launch_bounds__(64 * WPB) void k_pat31(const uint8_t *__restrict__ 
         }
     }
 }
+
+// pitch experiment: the same strip copy but rows are `pitch` bytes apart (pitch >= w): does a non power-of-two row stride help?
+template <int R, int C, int NT>
+__global__ __launch_bounds__(256) void k_strip_copy_pitch(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int groups_x, size_t pitch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned t = blockIdx.x;
+    const int gx_i = (int)(t % (unsigned)groups_x), gy_i = (int)(t / (unsigned)groups_x);
+    const int xw = (gx_i * 4 + wave) * 1024;
+    const int x = xw + 16 * lane;
+    const int y0 = gy_i * R;
+    if (xw >= w || x >= w) return;
+    constexpr int NCH = (R + C - 1) / C;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        uint4 q[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int yy = y0 + ch * C + j;
+            q[j] = make_uint4(0, 0, 0, 0);
+            if (yy < rows) q[j] = ldg<NT>(reinterpret_cast<const uint4 *>(src + (size_t)yy * pitch + x));
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int yy = y0 + ch * C + j;
+            if (yy < rows) stg<NT>(reinterpret_cast<uint4 *>(dst + (size_t)yy * pitch + x), q[j]);
+        }
+    }
+}
 }  // namespace ubp
 
 static void bench_pattern(int W, int H)
@@ -807,4 +836,27 @@ static void bench_pattern31(int W, int H)
     P31L(32, 2, 20); P31L(32, 2, 26); P31L(32, 2, 32); P31L(32, 2, 40); P31L(32, 2, 53); P31L(32, 2, 80); P31L(32, 4, 53); P31L(32, 6, 53); P31L(32, 4, 80); P31L(32, 8, 80);
     run_table("access-pattern ceiling: 3R+1W (fused shape)", vs, (double)npix);
     CK(hipFree(rgb)); CK(hipFree(out));
+}
+
+static void bench_pitch(int W, int H)
+{
+    using namespace ubp;
+    const size_t maxpitch = (size_t)W + 8192;
+    uint8_t *src, *out;
+    CK(hipMalloc(&src, maxpitch * H + 4096)); CK(hipMalloc(&out, maxpitch * H + 4096 + 1024));
+    k_fill<<<4096, 256>>>((uint32_t *)src, maxpitch * H / 4, 5);
+    std::vector<Variant> vs;
+    const int gx = (W + 4095) / 4096;
+    const double npix = (double)W * H;
+    for (size_t pad : {0, 256, 512, 1024, 2048, 4096, 4352, 8192, 128, 768}) {
+        const size_t pitch = (size_t)W + pad;
+        vs.push_back({"strip copy R32 C2 nt1 pitch=w+" + std::to_string(pad), [=] { k_strip_copy_pitch<32, 2, 1><<<gx * ((H + 31) / 32), 256>>>(src, out, W, H, gx, pitch); }, 2.0 * npix});
+    }
+    for (size_t pad : {0, 256, 1024}) {
+        const size_t pitch = (size_t)W + pad;
+        vs.push_back({"strip copy R16 C4 nt1 pitch=w+" + std::to_string(pad), [=] { k_strip_copy_pitch<16, 4, 1><<<gx * ((H + 15) / 16), 256>>>(src, out, W, H, gx, pitch); }, 2.0 * npix});
+        vs.push_back({"strip copy R32 C2 dst+1024 pitch=w+" + std::to_string(pad), [=] { k_strip_copy_pitch<32, 2, 1><<<gx * ((H + 31) / 32), 256>>>(src, out + 1024, W, H, gx, pitch); }, 2.0 * npix});
+    }
+    run_table("row-pitch experiment: 1R+1W strip copy", vs, npix);
+    CK(hipFree(src)); CK(hipFree(out));
 }
