@@ -11,8 +11,8 @@
 //     the first/last sample of a row not interpolated;
 //   * YCbCr -> RGB in 20-bit fixed point with constants round(c * 4096) << 8, the Cb contribution to G
 //     truncated to a multiple of 2^16, +0.5 rounding, >> 20, clamp.
-// tests/test_cli_image_io.py checks it pixel-for-pixel against the reference's own decoder compiled in
-// place (oracle/_ref/stb_decode) on the reference's three JPEGs (baseline 4:4:4, progressive 4:2:0).
+// tests/test_cli_image_io.py checks it pixel-for-pixel against the reference's own decoder (compiled in
+// place in the build container) on the reference's three JPEGs (baseline 4:4:4, progressive 4:2:0).
 // Written from the JPEG standard (ITU T.81) and the behaviour above; no third-party code is included.
 #include "image_io.h"
 
