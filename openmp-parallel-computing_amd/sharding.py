@@ -54,6 +54,43 @@ class HipBackend:
     def sum_rgb(self, rgb):
         return self.api.sum_rgb_dev(rgb)
 
+    # Pre-bound launchers: at 8 GPUs a shard's kernels take ~30 us, so per-step Python overhead matters.
+    # Pointers, sizes and flags are resolved once; the returned closure is one ctypes call.
+    def bind_sobel_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        import torch
+        lib, chk = self.api.abi.load(), self.api.check
+        w = buf.shape[1]
+        assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w) and buf.is_contiguous() and out.is_contiguous()
+        src, dst, t, b = buf.data_ptr() + w, out.data_ptr(), int(top_is_border), int(bottom_is_border)
+        fn = lib.gh_sobel_u8_rows_dev
+        return lambda: chk(fn(src, dst, w, rows, t, b, torch.cuda.current_stream().cuda_stream), "sobel_rows")
+
+    def bind_fused_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        import torch
+        lib, chk = self.api.abi.load(), self.api.check
+        w, c = buf.shape[1], buf.shape[2]
+        assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w) and buf.is_contiguous() and out.is_contiguous()
+        src, dst, t, b, mode = buf.data_ptr() + w * c, out.data_ptr(), int(top_is_border), int(bottom_is_border), self.mode
+        fn = lib.gh_gray_sobel_fused_rows_dev
+        return lambda: chk(fn(src, dst, w, rows, c, mode, t, b, torch.cuda.current_stream().cuda_stream), "fused_rows")
+
+    def bind_gray_to_plane(self, rgb, out):
+        import torch
+        lib, chk = self.api.abi.load(), self.api.check
+        h, w, c = rgb.shape
+        assert rgb.is_contiguous() and out.is_contiguous() and out.numel() == h * w
+        src, dst, mode = rgb.data_ptr(), out.data_ptr(), self.mode
+        fn = lib.gh_gray_rgb8_to_plane_dev
+        return lambda: chk(fn(src, dst, h * w, c, mode, torch.cuda.current_stream().cuda_stream), "gray_to_plane")
+
+
+def _bind(backend, name, generic, *args):
+    """Use the backend's pre-bound launcher when it has one (HipBackend), else wrap the generic call."""
+    binder = getattr(backend, "bind_" + name, None)
+    if binder is not None:
+        return binder(*args)
+    return lambda: generic(*args)
+
 
 @dataclass
 class ShardGeometry:
@@ -89,21 +126,39 @@ class ShardedGraySobel:
         self.backend = backend
         self.group = group
         self.overlap = overlap
-        self.luma = torch.zeros((geom.rows + 2, geom.width), dtype=torch.uint8, device=device)
-        self.edge = torch.empty((geom.rows, geom.width), dtype=torch.uint8, device=device)
+        rows = geom.rows
+        self.luma = torch.zeros((rows + 2, geom.width), dtype=torch.uint8, device=device)
+        self.edge = torch.empty((rows, geom.width), dtype=torch.uint8, device=device)
+        self._ops = None
+        self._gray_for = None          # (data_ptr of the last rgb shard, bound launcher)
+        b, g = backend, geom
+        if rows == 0:
+            return
+        if g.world == 1:
+            self._whole = _bind(b, "sobel_rows", b.sobel_rows, self.luma, self.edge, rows, True, True)
+        elif overlap and rows >= 3:
+            # rows 1..rows-2 of the band depend on local luma only: a band whose "halo" rows are band rows 0 / rows-1
+            self._inner = _bind(b, "sobel_rows", b.sobel_rows, self.luma[1:rows + 1], self.edge[1:rows - 1], rows - 2, False, False)
+            self._top = _bind(b, "sobel_rows", b.sobel_rows, self.luma[0:3], self.edge[0:1], 1, g.top_is_border, False)
+            self._bot = _bind(b, "sobel_rows", b.sobel_rows, self.luma[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+        else:
+            self.overlap = False
+            self._whole = _bind(b, "sobel_rows", b.sobel_rows, self.luma, self.edge, rows, g.top_is_border, g.bottom_is_border)
 
     # -- halo exchange: my first luma row goes up, my last goes down --------------------------
     def _exchange_ops(self):
         import torch.distributed as dist
-        g, buf = self.g, self.luma
-        ops = []
-        if not g.top_is_border:
-            ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
-        if not g.bottom_is_border:
-            ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
-        return ops
+        if self._ops is None:
+            g, buf = self.g, self.luma
+            ops = []
+            if not g.top_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
+            if not g.bottom_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
+            self._ops = ops
+        return self._ops
 
     def step(self, rgb_shard):
         import torch.distributed as dist
@@ -111,24 +166,25 @@ class ShardedGraySobel:
         rows = g.rows
         if rows == 0:
             return self.edge
-        self.backend.gray_to_plane(rgb_shard, self.luma[1:rows + 1])
+        if self._gray_for is None or self._gray_for[0] != rgb_shard.data_ptr():
+            self._gray_for = (rgb_shard.data_ptr(),
+                              _bind(self.backend, "gray_to_plane", self.backend.gray_to_plane, rgb_shard, self.luma[1:rows + 1]))
+        self._gray_for[1]()
         if g.world == 1:
-            self.backend.sobel_rows(self.luma, self.edge, rows, True, True)
+            self._whole()
             return self.edge
         ops = self._exchange_ops()
         works = dist.batch_isend_irecv(ops) if ops else []
-        if self.overlap and rows >= 3:
-            # rows 1..rows-2 of the band depend on local luma only
-            inner = self.luma[1:rows + 1]          # (rows, w): a band whose "halo" rows are band rows 0 / rows-1
-            self.backend.sobel_rows(inner, self.edge[1:rows - 1], rows - 2, False, False)
+        if self.overlap:
+            self._inner()
             for wk in works:
                 wk.wait()
-            self.backend.sobel_rows(self.luma[0:3], self.edge[0:1], 1, g.top_is_border, False)
-            self.backend.sobel_rows(self.luma[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+            self._top()
+            self._bot()
         else:
             for wk in works:
                 wk.wait()
-            self.backend.sobel_rows(self.luma, self.edge, rows, g.top_is_border, g.bottom_is_border)
+            self._whole()
         return self.edge
 
 
@@ -147,8 +203,22 @@ class ShardedFusedGraySobel:
         self.backend = backend
         self.group = group
         self.overlap = overlap
-        self.rgb = torch.zeros((geom.rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
-        self.edge = torch.empty((geom.rows, geom.width), dtype=torch.uint8, device=device)
+        rows = geom.rows
+        self.rgb = torch.zeros((rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
+        self.edge = torch.empty((rows, geom.width), dtype=torch.uint8, device=device)
+        self._ops = None
+        b, g = backend, geom
+        if rows == 0:
+            return
+        if g.world == 1:
+            self._whole = _bind(b, "fused_rows", b.fused_rows, self.rgb, self.edge, rows, True, True)
+        elif overlap and rows >= 3:
+            self._inner = _bind(b, "fused_rows", b.fused_rows, self.rgb[1:rows + 1], self.edge[1:rows - 1], rows - 2, False, False)
+            self._top = _bind(b, "fused_rows", b.fused_rows, self.rgb[0:3], self.edge[0:1], 1, g.top_is_border, False)
+            self._bot = _bind(b, "fused_rows", b.fused_rows, self.rgb[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+        else:
+            self.overlap = False
+            self._whole = _bind(b, "fused_rows", b.fused_rows, self.rgb, self.edge, rows, g.top_is_border, g.bottom_is_border)
 
     @property
     def shard(self):
@@ -156,37 +226,38 @@ class ShardedFusedGraySobel:
 
     def _exchange_ops(self):
         import torch.distributed as dist
-        g, buf = self.g, self.rgb
-        ops = []
-        if not g.top_is_border:
-            ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
-        if not g.bottom_is_border:
-            ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
-        return ops
+        if self._ops is None:
+            g, buf = self.g, self.rgb
+            ops = []
+            if not g.top_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
+            if not g.bottom_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
+            self._ops = ops
+        return self._ops
 
     def step(self):
         import torch.distributed as dist
         g = self.g
-        rows = g.rows
-        if rows == 0:
+        if g.rows == 0:
             return self.edge
         if g.world == 1:
-            self.backend.fused_rows(self.rgb, self.edge, rows, True, True)
+            self._whole()
             return self.edge
         ops = self._exchange_ops()
         works = dist.batch_isend_irecv(ops) if ops else []
-        if self.overlap and rows >= 3:
-            self.backend.fused_rows(self.rgb[1:rows + 1], self.edge[1:rows - 1], rows - 2, False, False)
+        if self.overlap:
+            self._inner()
             for wk in works:
                 wk.wait()
-            self.backend.fused_rows(self.rgb[0:3], self.edge[0:1], 1, g.top_is_border, False)
-            self.backend.fused_rows(self.rgb[rows - 1:rows + 2], self.edge[rows - 1:rows], 1, False, g.bottom_is_border)
+            self._top()
+            self._bot()
         else:
             for wk in works:
                 wk.wait()
-            self.backend.fused_rows(self.rgb, self.edge, rows, g.top_is_border, g.bottom_is_border)
+            self._whole()
         return self.edge
 
 
