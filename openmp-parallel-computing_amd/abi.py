@@ -49,6 +49,7 @@ SIGNATURES = {
     "gh_sobel_edge_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int]),
     "gh_pipeline_gray_sobel_host": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gh_sum_rgb8_host": (C.c_int, [_u8p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "gh_gray_sobel_streamed_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "convert_to_grayscale": (None, [_u8p, C.c_int, C.c_int, C.c_int]),
     "sobel_edge": (None, [_u8p, _u8p, C.c_int, C.c_int]),
     "gh_selftest_sobel_mag": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),

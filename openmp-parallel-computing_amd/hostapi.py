@@ -66,6 +66,19 @@ def pipeline_gray_sobel(img: np.ndarray, width: int, height: int, channels: int,
     return secs.value
 
 
+def gray_sobel_streamed(rgb: np.ndarray, edge: np.ndarray, tile_rows: int = 4096, mode: int = MODE_IEEE,
+                        pinned: bool = False) -> float:
+    """Streamed gray+Sobel of a host-resident (h, w, c) frame into a host (h, w) edge plane, band by band with
+    H2D / kernel / D2H overlapped on three hipStreams; returns the seconds spent in the pipelined loop."""
+    h, w, c = rgb.shape
+    if edge.shape != (h, w):
+        raise GrayHipError("edge must be (h, w)")
+    secs = C.c_double(0.0)
+    check(abi.load().gh_gray_sobel_streamed_host(_host_ptr(rgb, False), _host_ptr(edge, True), w, h, c, mode, tile_rows,
+                                                 int(pinned), C.byref(secs)), "gray_sobel_streamed")
+    return secs.value
+
+
 def sum_rgb(rgb: np.ndarray) -> list[int]:
     """Exact per-channel sums of an RGB8 frame (old/parallel_avg_pixel.c restated)."""
     s = (C.c_uint64 * 3)()

@@ -357,3 +357,16 @@ def test_sharded_runners_on_one_device(pkg, oracle, torch_mod, world, w, h):
         got_fused[y0:y1] = fused[r].edge
     assert np.array_equal(got_split.cpu().numpy(), want)
     assert np.array_equal(got_fused.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,ch,tile_rows", [(1024, 100, 3, 32), (2048, 64, 3, 64), (64, 7, 4, 1), (4096, 333, 3, 50), (16, 3, 3, 2)])
+def test_streamed_bands_equal_whole_frame(pkg, oracle, w, h, ch, tile_rows):
+    """BASELINE configs[4] at test size: host frame -> bands over 3 hipStreams -> host edge plane == unstreamed result."""
+    img = oracle.frame_rand(w, h, ch, seed=w + h + ch)
+    edge = np.full((h, w), 0x77, dtype=np.uint8)
+    secs = pkg.hostapi.gray_sobel_streamed(img, edge, tile_rows=tile_rows)
+    assert secs > 0
+    assert np.array_equal(edge, oracle.sobel(oracle.gray_to_plane(img, 0)))
+    edge2 = np.zeros_like(edge)
+    pkg.hostapi.gray_sobel_streamed(img, edge2, tile_rows=tile_rows, mode=1)
+    assert np.array_equal(edge2, oracle.sobel(oracle.gray_to_plane(img, 1)))
