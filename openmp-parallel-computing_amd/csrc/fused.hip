@@ -271,9 +271,11 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             }                                                                                                             \
         } while (0)
         // strip height: taller strips re-read fewer halo rows (2 per strip) but a shard must still fill the 256 CUs
-        const long long bands16 = (rows + 15) / 16;
         int pick = variant;
-        if (pick == 0) pick = (groups_x * ((bands16 + 3) / 4) >= 2048) ? 64 : ((groups_x * ((bands16 + 1) / 2) >= 1024) ? 32 : 16);
+        if (pick == 0) {
+            const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+            pick = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);     // >= 4 workgroups per CU
+        }
         switch (pick) {
         case 64: GH_FUSED_LAUNCH(64, 2, 1); break;
         case 32: GH_FUSED_LAUNCH(32, 2, 1); break;

@@ -201,13 +201,34 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
     static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
     if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst) && !use_tile) {
-        constexpr int R = 16, C = 2;
         static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
-        const int groups_x = (width + stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK - 1) / (stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK);
+        static const int r_env = [] { const char *e = getenv("GH_SOBEL_R"); return e ? atoi(e) : 0; }();   // tuning knob
+        const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
+        const int groups_x = (width + span - 1) / span;
+        // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 62)
+        // but a shard must still give every CU a few workgroups
+        int R = r_env;
+        if (R != 14 && R != 30 && R != 62 && R != 16 && R != 32 && R != 64) {
+            const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+            R = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);     // >= 4 workgroups per CU
+        }
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        if (core == 0) k_sobel_stream<R, C, 0><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
-        else k_sobel_stream<R, C, 1><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);
+        const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
+#define GH_SOBEL_LAUNCH(R_, C_)                                                                                      \
+        do {                                                                                                         \
+            if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);       \
+            else k_sobel_stream<R_, C_, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);                 \
+        } while (0)
+        switch (R) {
+        case 64: GH_SOBEL_LAUNCH(64, 2); break;
+        case 32: GH_SOBEL_LAUNCH(32, 2); break;
+        case 62: GH_SOBEL_LAUNCH(62, 4); break;     // tuning: 4-row chunks
+        case 30: GH_SOBEL_LAUNCH(30, 4); break;
+        case 14: GH_SOBEL_LAUNCH(14, 4); break;
+        default: GH_SOBEL_LAUNCH(16, 2); break;
+        }
+#undef GH_SOBEL_LAUNCH
     } else if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst)) {
         const int tiles_x = (width + TW - 1) / TW;
         const int tiles_y = (rows + TH - 1) / TH;
