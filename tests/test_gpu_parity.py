@@ -370,3 +370,18 @@ def test_streamed_bands_equal_whole_frame(pkg, oracle, w, h, ch, tile_rows):
     edge2 = np.zeros_like(edge)
     pkg.hostapi.gray_sobel_streamed(img, edge2, tile_rows=tile_rows, mode=1)
     assert np.array_equal(edge2, oracle.sobel(oracle.gray_to_plane(img, 1)))
+
+
+@pytest.mark.parametrize("w,h", [(16, 1), (16, 5), (32, 33), (1024, 31), (1040, 40), (2048, 70), (4096, 9), (352, 100)])
+def test_conv3x3_streaming_path(pkg, oracle, torch_mod, w, h):
+    """old/parallel_convolution.c on u8 frames, strip-streaming kernel (3*w % 16 == 0): blur, sharpen, gradient kernels,
+    negative and large divisors, and the fallback beyond the fast path's exactness conditions."""
+    img = oracle.frame_rand(w, h, 3, seed=w * 3 + h)
+    d = dev(torch_mod, img)
+    cases = [([1, 2, 1, 2, 4, 2, 1, 2, 1], 16), ([1] * 9, 9), ([0, -1, 0, -1, 5, -1, 0, -1, 0], 1), ([-1, -2, -1, 0, 0, 0, 1, 2, 1], 3),
+             ([1, 2, 3, 4, 5, 6, 7, 8, 9], 7), ([1, 2, 1, 2, 4, 2, 1, 2, 1], -16), ([-3, 0, 3, -10, 0, 10, -3, 0, 3], -2),
+             ([100, 200, 100, 200, 400, 200, 100, 200, 100], 4096), ([7, 7, 7, 7, 7, 7, 7, 7, 7], 5000), ([0] * 9, 3),
+             ([255, 255, 255, 255, 255, 255, 255, 255, 255], 1)]
+    for k, norm in cases:
+        got = pkg.hostapi.conv3x3(d, k, norm).cpu().numpy()
+        assert np.array_equal(got, oracle.conv3x3(img, k, norm)), (w, h, k, norm)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Times every device-resident kernel of the C ABI on a 16384^2 frame (developer tool; bench.py is the contract bench)."""
+import importlib, os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("openmp-parallel-computing_amd"); api = pkg.hostapi; api.init(0)
+W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+npix = W * H
+rgb = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda")
+rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda")
+plane = torch.empty((H, W), dtype=torch.uint8, device="cuda"); plane2 = torch.empty_like(plane); out3 = torch.empty_like(rgb)
+def t(fn, reps=20):
+    for _ in range(3): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); [fn() for _ in range(reps)]; b.record(); b.synchronize(); return a.elapsed_time(b) / reps
+rows = []
+def add(name, bpp, fn):
+    ms = t(fn); rows.append((name, bpp, ms, bpp * npix / ms / 1e6))
+add("gray_rgb8_to_plane", 4, lambda: api.gray_to_plane(rgb, 0, out=plane))
+add("gray_rgba8_to_plane", 5, lambda: api.gray_to_plane(rgba, 0, out=plane))
+add("gray_inplace_rgb8", 6, lambda: api.gray_inplace(out3, 0))
+add("gray_inplace_rgba8", 8, lambda: api.gray_inplace(rgba, 0))
+add("sobel3x3_u8", 2, lambda: api.sobel(plane, out=plane2))
+add("gray_sobel_fused_rgb8", 4, lambda: api.gray_sobel_fused(rgb, 0, out=plane2))
+add("gray_sobel_fused_rgba8", 5, lambda: api.gray_sobel_fused(rgba, 0, out=plane2))
+add("extract_plane_rgb8", 4, lambda: api.extract_plane(rgb, out=plane))
+add("replicate_plane_rgb8", 4, lambda: api.replicate_plane(plane, out3))
+add("gray_of_plane", 2, lambda: api.gray_of_plane(plane, 0, out=plane2))
+sums = torch.zeros(3, dtype=torch.int64, device="cuda")
+lib = pkg.abi.load()
+add("sum_rgb8", 3, lambda: pkg.abi.check(lib.gh_sum_rgb8_dev(rgb.data_ptr(), npix, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+mm = torch.tensor([256, -1], dtype=torch.int32, device="cuda")
+add("mean_gray_minmax_rgb8", 6, lambda: pkg.abi.check(lib.gh_mean_gray_minmax_dev(rgb.data_ptr(), out3.data_ptr(), npix, mm.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+add("conv3x3_rgb8 (gauss/16)", 6, lambda: api.conv3x3(rgb, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16, out=out3))
+print(f"{'kernel':28s} {'B/px':>5s} {'ms':>9s} {'GB/s':>9s} {'%8TB/s':>7s} {'Gpx/s':>8s}")
+for name, bpp, ms, gbs in rows:
+    print(f"{name:28s} {bpp:5d} {ms:9.4f} {gbs:9.1f} {gbs/80:7.1f} {npix/ms/1e6:8.1f}")
