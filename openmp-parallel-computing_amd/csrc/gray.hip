@@ -60,23 +60,21 @@ __global__ __launch_bounds__(BLOCK) void k_gray_rgb_to_plane_w(const uint4 *__re
 {
     __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint4 *sw = reinterpret_cast<uint4 *>(slab[wave]);
-    const uint4 *sr = reinterpret_cast<const uint4 *>(slab[wave] + 48 * lane);
     const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
     for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
-        const uint4 *p = in + g * 192;
-        const uint4 v0 = stream_core::load_stream(p + lane);
-        const uint4 v1 = stream_core::load_stream(p + 64 + lane);
-        const uint4 v2 = stream_core::load_stream(p + 128 + lane);
-        sw[lane] = v0; sw[64 + lane] = v1; sw[128 + lane] = v2;
-        __builtin_amdgcn_wave_barrier();      // one wave, DS ops in order: scheduling fence only
-        const uint4 a = sr[0], b = sr[1], c = sr[2];
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        uint32_t lum[16];
+        uint32_t w[12], lum[16];
+        stream_core::wave_load_rgb48(slab[wave], in + g * 192, lane, w);
         luma16_rgb<MODE>(w, lum);
         stream_core::store_stream(out + g * 64 + lane, pack16(lum));
     }
+}
+
+// byte k of the 48 replicated output bytes is v[k / 3]
+__device__ __forceinline__ void replicate48(const uint32_t (&v)[16], uint32_t (&o)[12])
+{
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+        o[j] = v[(4 * j) / 3] | (v[(4 * j + 1) / 3] << 8) | (v[(4 * j + 2) / 3] << 16) | (v[(4 * j + 3) / 3] << 24);
 }
 
 // in place: same read path; the 48 replicated output bytes go back through the slab so the stores are coalesced too
@@ -85,32 +83,44 @@ __global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb_w(uint4 *__restrict_
 {
     __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint4 *sw = reinterpret_cast<uint4 *>(slab[wave]);
-    uint4 *sl = reinterpret_cast<uint4 *>(slab[wave] + 48 * lane);
     const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
     for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
-        uint4 *p = data + g * 192;
-        const uint4 v0 = stream_core::load_stream(p + lane);
-        const uint4 v1 = stream_core::load_stream(p + 64 + lane);
-        const uint4 v2 = stream_core::load_stream(p + 128 + lane);
-        sw[lane] = v0; sw[64 + lane] = v1; sw[128 + lane] = v2;
-        __builtin_amdgcn_wave_barrier();
-        const uint4 a = sl[0], b = sl[1], c = sl[2];
-        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        uint32_t lum[16], o[12];
+        uint32_t w[12], lum[16], o[12];
+        stream_core::wave_load_rgb48(slab[wave], data + g * 192, lane, w);
         luma16_rgb<MODE>(w, lum);
+        replicate48(lum, o);
+        stream_core::wave_store_rgb48(slab[wave], data + g * 192, lane, o);
+    }
+}
+
+// plane extract / replicate (main_with_sobel.c:57-59, 65-73), wavefront form
+__global__ __launch_bounds__(BLOCK) void k_extract_rgb_w(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t nwavegroups)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
+    for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
+        uint32_t w[12], v[16];
+        stream_core::wave_load_rgb48(slab[wave], in + g * 192, lane, w);
 #pragma unroll
-        for (int j = 0; j < 12; ++j)
-            o[j] = lum[(4 * j) / 3] | (lum[(4 * j + 1) / 3] << 8) | (lum[(4 * j + 2) / 3] << 16) | (lum[(4 * j + 3) / 3] << 24);
-        sl[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        sl[1] = make_uint4(o[4], o[5], o[6], o[7]);
-        sl[2] = make_uint4(o[8], o[9], o[10], o[11]);
-        __builtin_amdgcn_wave_barrier();
-        const uint4 r0 = sw[lane], r1 = sw[64 + lane], r2 = sw[128 + lane];
-        __builtin_amdgcn_wave_barrier();
-        stream_core::store_stream(p + lane, r0);
-        stream_core::store_stream(p + 64 + lane, r1);
-        stream_core::store_stream(p + 128 + lane, r2);
+        for (int p = 0; p < 16; ++p) v[p] = gh_byte(w[(3 * p) >> 2], (3 * p) & 3);
+        stream_core::store_stream(out + g * 64 + lane, pack16(v));
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_replicate_rgb_w(const uint4 *__restrict__ plane, uint4 *__restrict__ img, size_t nwavegroups)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
+    for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
+        const uint4 q = stream_core::load_stream(plane + g * 64 + lane);
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        uint32_t v[16], o[12];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = gh_byte(w4[p >> 2], p & 3);
+        replicate48(v, o);
+        stream_core::wave_store_rgb48(slab[wave], img + g * 192, lane, o);
     }
 }
 
@@ -417,8 +427,11 @@ int gh_extract_plane_dev(const uint8_t *img, uint8_t *plane, size_t npix, int ch
     hipStream_t s = (hipStream_t)stream;
     size_t done = 0;
     if (channels == 3 && gh_aligned16(img) && gh_aligned16(plane) && npix >= PX_PER_LANE) {
-        const size_t ngroups = npix / PX_PER_LANE;
-        k_extract_rgb<<<grid_for(ngroups), BLOCK, 0, s>>>(reinterpret_cast<const uint4 *>(img), reinterpret_cast<uint4 *>(plane), ngroups);
+        const size_t ngroups = npix / PX_PER_LANE, nwg = ngroups / 64, rest = ngroups - nwg * 64;
+        auto in = reinterpret_cast<const uint4 *>(img);
+        auto out = reinterpret_cast<uint4 *>(plane);
+        if (nwg) k_extract_rgb_w<<<grid_for(nwg * 64), BLOCK, 0, s>>>(in, out, nwg);
+        if (rest) k_extract_rgb<<<1, BLOCK, 0, s>>>(in + nwg * 192, out + nwg * 64, rest);
         GH_LAUNCH_CHECK();
         done = ngroups * PX_PER_LANE;
     }
@@ -438,8 +451,11 @@ int gh_replicate_plane_dev(const uint8_t *plane, uint8_t *img, size_t npix, int 
     hipStream_t s = (hipStream_t)stream;
     size_t done = 0;
     if (channels == 3 && gh_aligned16(img) && gh_aligned16(plane) && npix >= PX_PER_LANE) {
-        const size_t ngroups = npix / PX_PER_LANE;
-        k_replicate_rgb<<<grid_for(ngroups), BLOCK, 0, s>>>(reinterpret_cast<const uint4 *>(plane), reinterpret_cast<uint4 *>(img), ngroups);
+        const size_t ngroups = npix / PX_PER_LANE, nwg = ngroups / 64, rest = ngroups - nwg * 64;
+        auto in = reinterpret_cast<const uint4 *>(plane);
+        auto out = reinterpret_cast<uint4 *>(img);
+        if (nwg) k_replicate_rgb_w<<<grid_for(nwg * 64), BLOCK, 0, s>>>(in, out, nwg);
+        if (rest) k_replicate_rgb<<<1, BLOCK, 0, s>>>(in + nwg * 64, out + nwg * 192, rest);
         GH_LAUNCH_CHECK();
         done = ngroups * PX_PER_LANE;
     }

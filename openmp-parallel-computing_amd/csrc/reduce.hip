@@ -9,6 +9,7 @@
 // 64-lane wavefront is folded with __shfl_down, the 4 waves of a workgroup through LDS, and one
 // atomic per workgroup and channel reaches HBM.  Bound: HBM, 3 R bytes per pixel (+3 W for mean).
 #include "gh_common.h"
+#include "stream_core.h"
 
 namespace {
 
@@ -37,19 +38,24 @@ __global__ __launch_bounds__(BLOCK) void k_sum_rgb(const uint8_t *__restrict__ r
                                                    unsigned long long *__restrict__ sums)
 {
     __shared__ unsigned long long part[BLOCK / 64][3];
+    __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
     unsigned long long acc[3] = {0, 0, 0};
     const size_t stride = (size_t)gridDim.x * BLOCK;
-    const size_t ngroups = vec_ok ? npix / 16 : 0;
+    const size_t nwg = vec_ok ? npix / 1024 : 0;             // whole wavefront groups of 1024 px
     const uint4 *in = reinterpret_cast<const uint4 *>(rgb);
-    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
-        const uint4 a = in[3 * g], b = in[3 * g + 1], c = in[3 * g + 2];
-        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        uint32_t s[3] = {0, 0, 0};
+    {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        const size_t wstride = (size_t)gridDim.x * (BLOCK / 64);
+        for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave_; g < nwg; g += wstride) {
+            uint32_t w[12];
+            stream_core::wave_load_rgb48(slab[wave_], in + g * 192, lane_, w);
+            uint32_t s[3] = {0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 48; ++k) s[k % 3] += gh_byte(w[k >> 2], k & 3);
-        acc[0] += s[0]; acc[1] += s[1]; acc[2] += s[2];
+            for (int k = 0; k < 48; ++k) s[k % 3] += gh_byte(w[k >> 2], k & 3);
+            acc[0] += s[0]; acc[1] += s[1]; acc[2] += s[2];
+        }
     }
-    for (size_t i = ngroups * 16 + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+    for (size_t i = nwg * 1024 + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
         acc[0] += rgb[3 * i]; acc[1] += rgb[3 * i + 1]; acc[2] += rgb[3 * i + 2];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,14 +77,17 @@ __global__ __launch_bounds__(BLOCK) void k_mean_minmax(const uint8_t *__restrict
                                                        int vec_ok, int *__restrict__ minmax)
 {
     __shared__ int pmin[BLOCK / 64], pmax[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
     int lo = 256, hi = -1;
     const size_t stride = (size_t)gridDim.x * BLOCK;
-    const size_t ngroups = vec_ok ? npix / 16 : 0;
+    const size_t nwg = vec_ok ? npix / 1024 : 0;
     const uint4 *in = reinterpret_cast<const uint4 *>(rgb);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
-    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
-        const uint4 a = in[3 * g], b = in[3 * g + 1], c = in[3 * g + 2];
-        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const size_t wstride = (size_t)gridDim.x * (BLOCK / 64);
+    for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave_; g < nwg; g += wstride) {
+        uint32_t w[12];
+        stream_core::wave_load_rgb48(slab[wave_], in + g * 192, lane_, w);
         uint32_t m[16], o[12];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -91,11 +100,9 @@ __global__ __launch_bounds__(BLOCK) void k_mean_minmax(const uint8_t *__restrict
 #pragma unroll
         for (int j = 0; j < 12; ++j)
             o[j] = m[(4 * j) / 3] | (m[(4 * j + 1) / 3] << 8) | (m[(4 * j + 2) / 3] << 16) | (m[(4 * j + 3) / 3] << 24);
-        o4[3 * g] = make_uint4(o[0], o[1], o[2], o[3]);
-        o4[3 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-        o4[3 * g + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+        stream_core::wave_store_rgb48(slab[wave_], o4 + g * 192, lane_, o);
     }
-    for (size_t i = ngroups * 16 + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
+    for (size_t i = nwg * 1024 + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
         const int g = ((int)rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3;
         out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = (uint8_t)g;
         lo = min(lo, g);
