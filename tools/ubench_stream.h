@@ -857,6 +857,9 @@ static void bench_pitch(int W, int H)
         vs.push_back({"strip copy R16 C4 nt1 pitch=w+" + std::to_string(pad), [=] { k_strip_copy_pitch<16, 4, 1><<<gx * ((H + 15) / 16), 256>>>(src, out, W, H, gx, pitch); }, 2.0 * npix});
         vs.push_back({"strip copy R32 C2 dst+1024 pitch=w+" + std::to_string(pad), [=] { k_strip_copy_pitch<32, 2, 1><<<gx * ((H + 31) / 32), 256>>>(src, out + 1024, W, H, gx, pitch); }, 2.0 * npix});
     }
+    // band-height experiment: is a power-of-two band stride (R * pitch) the problem?
+#define PR(R_, C_) vs.push_back({"strip copy R" #R_ " C" #C_ " nt1 pitch=w", [=] { k_strip_copy_pitch<R_, C_, 1><<<gx * ((H + R_ - 1) / R_), 256>>>(src, out, W, H, gx, (size_t)W); }, 2.0 * npix})
+    PR(32, 2); PR(30, 2); PR(34, 2); PR(31, 1); PR(33, 1); PR(28, 2); PR(36, 2); PR(62, 2); PR(64, 2); PR(66, 2); PR(60, 2); PR(48, 2); PR(46, 2); PR(50, 2); PR(24, 2); PR(22, 2); PR(26, 2); PR(16, 2); PR(14, 2); PR(18, 2); PR(126, 2); PR(128, 2); PR(130, 2); PR(8, 2); PR(10, 2); PR(6, 2);
     run_table("row-pitch experiment: 1R+1W strip copy", vs, npix);
     CK(hipFree(src)); CK(hipFree(out));
 }
