@@ -60,6 +60,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(kernel_name: str, px: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction), scaled to this launch's
+    pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself."""
+    sym = {"gray_sobel_fused_rgb8": "k_fused_stream", "gray_rgb8_to_plane": "k_gray_rgb_to_plane_w", "sobel3x3_u8": "k_sobel_stream"}
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic.json")), key=os.path.getmtime, reverse=True):
+            k = json.load(open(f)).get("kernels", {}).get(sym[kernel_name])
+            if k and "hbm_total_bytes" in k:
+                return int(k["hbm_total_bytes"] / (16384 * 16384) * px), os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(width: int, sample_rows: int) -> dict:
     """The reference's OpenMP CPU path on this box's host cores, kernel-only timing (clock around the calls like
     monolithic/src/main.c:30-38), on a bounded sample: the first `sample_rows` rows of the frame.  Uses the
@@ -274,8 +290,9 @@ def main() -> int:
         if timed_kernels:
             dom = max(timed_kernels, key=timed_kernels.get)
             a = kern_table[dom]["GB/s"]
+            traffic, traffic_src = measured_traffic(dom, px_rank)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"]}
         else:
             # N > 1: the step interleaves kernels with the RCCL exchange; report the step's aggregate traffic rate per rank

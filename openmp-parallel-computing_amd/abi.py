@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libgrayhip.so")
+LIB_PATH = os.environ.get("GRAYHIP_LIB") or os.path.join(_PKG_DIR, "lib", "libgrayhip.so")   # override: A/B builds
 REPO_ROOT = os.path.dirname(_PKG_DIR)
 
 MODE_IEEE = 0

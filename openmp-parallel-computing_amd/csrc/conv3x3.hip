@@ -135,7 +135,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
             }
             if (i >= 2) {
                 const int y = y0 + i - 2;
-                if (in_frame && y < h) store_stream(reinterpret_cast<uint4 *>(dst + (size_t)y * wb + x), make_uint4(r[0], r[1], r[2], r[3]));
+                if (in_frame && y < h) store_strip(dst + (size_t)y * wb + xw, lane, make_uint4(r[0], r[1], r[2], r[3]));
             }
         }
     };

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
                 if (x == 0) out.x &= 0xffffff00u;
                 if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                 if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                if (in_frame && y < rows) store_stream(reinterpret_cast<uint4 *>(edge + (size_t)y * w + x), out);
+                if (in_frame && y < rows) store_strip(edge + (size_t)y * w + xw, lane, out);
             }
         }
     }

@@ -5,9 +5,10 @@
 //                  whole information, the division is done by the caller -- see gh_sum_rgb8_host)
 //   k_mean_minmax  g=(r+g+b)/3 + global min/max <- old/parallel_to_grayscale.c:7-38
 //
-// Each lane streams 16-pixel groups (3 x dwordx4), keeps integer partials in registers, then the
-// 64-lane wavefront is folded with __shfl_down, the 4 waves of a workgroup through LDS, and one
-// atomic per workgroup and channel reaches HBM.  Bound: HBM, 3 R bytes per pixel (+3 W for mean).
+// A wavefront streams 1024-pixel groups with three fully coalesced dwordx4 loads, re-sliced through a private LDS
+// slab so that each lane owns 16 pixels (stream_core::wave_load_rgb48); lanes keep integer partials in registers,
+// the 64-lane wavefront is folded with __shfl_down, the 4 waves of a workgroup through LDS, and one atomic per
+// workgroup and channel reaches HBM.  Bound: HBM, 3 R bytes per pixel (+3 W for mean).
 #include "gh_common.h"
 #include "stream_core.h"
 

@@ -248,6 +248,27 @@ __device__ __forceinline__ void wave_store_rgb48(uint8_t *slab, uint4 *p, int la
     store_stream(p + 128 + lane, r2);
 }
 
+// Output stores of the strip kernels.  STORE_POLICY: 0 = default, 1 = sc1 buffer store, 2 = nontemporal (default).
+// In the no-compute 3R:1W strip-copy probe (tools/ubench pattern31) default / sc1 stores beat nt stores by 8 %, but in the
+// real kernels the order flips: fused 0.2006 ms (nt) vs 0.2107 (default) vs 0.2129 (sc1); conv 0.325 / 0.342 / 0.344;
+// Sobel 0.105 / 0.101 / 0.103 -- so nt stays (build with -DGH_STRIP_STORE_POLICY=n to re-measure).
+#ifndef GH_STRIP_STORE_POLICY
+#define GH_STRIP_STORE_POLICY 2
+#endif
+__device__ __forceinline__ void store_strip(uint8_t *wave_row /* wave-uniform: first byte of this wave's 1 KiB piece */, int lane, const uint4 v)
+{
+#if GH_STRIP_STORE_POLICY == 1
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wave_row, 0, STRIP_PX, 0x00020000);
+    u32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 16 /* sc1 */);
+#elif GH_STRIP_STORE_POLICY == 2
+    store_stream(reinterpret_cast<uint4 *>(wave_row) + lane, v);
+#else
+    reinterpret_cast<uint4 *>(wave_row)[lane] = v;
+#endif
+}
+
 // 0.5f kept in a VGPR (opaque to the optimiser) so the fma above can take it as a register operand
 __device__ __forceinline__ float half_reg()
 {

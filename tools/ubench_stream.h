@@ -789,6 +789,45 @@ __global__ __launch_bounds__(256) void k_strip_copy_pitch(const uint8_t *__restr
         }
     }
 }
+
+// cache-policy experiment: 3R:1W strip copy with buffer loads/stores and explicit cpol bits
+//   aux bit0 = sc0, bit1 = nt, bit4 = sc1 (gfx940+ encoding of the LLVM cachepolicy immediate)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+template <int R, int C, int LAUX, int SAUX>
+__global__ __launch_bounds__(256) void k_pat31_cpol(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ dst, int w, int rows, int groups_x)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned t = blockIdx.x;
+    const int gx_i = (int)(t % (unsigned)groups_x), gy_i = (int)(t / (unsigned)groups_x);
+    const int xw = (gx_i * 4 + wave) * 1024;
+    const int x = xw + 16 * lane;
+    const int y0 = gy_i * R;
+    if (xw >= w || x >= w) return;
+    constexpr int NCH = (R + C - 1) / C;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        u32x4 a[C], b[C], c[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int yy = y0 + ch * C + j;
+            const uint8_t *rowp = rgb + ((size_t)yy * w + xw) * 3;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(rowp, 3072);
+            a[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, LAUX));
+            b[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 1024 + lane * 16, 0, LAUX));
+            c[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 2048 + lane * 16, 0, LAUX));
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int yy = y0 + ch * C + j;
+            u32x4 v = a[j] ^ b[j] ^ c[j];
+            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dst + (size_t)yy * w + xw, 1024);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rd, lane * 16, 0, SAUX);
+        }
+    }
+}
 }  // namespace ubp
 
 static void bench_pattern(int W, int H)
@@ -831,6 +870,8 @@ static void bench_pattern31(int W, int H)
 #define P31(R_, C_, NT_, WPB_) vs.push_back({"strip 3R:1W R" #R_ " C" #C_ " nt" #NT_ " waves/blk" #WPB_, [=] { const int g = (W + 1024 * WPB_ - 1) / (1024 * WPB_); k_pat31<R_, C_, NT_, WPB_><<<g * ((H + R_ - 1) / R_), 64 * WPB_>>>(rgb, out, W, H, g); }, 4.0 * npix})
     P31(32, 2, 1, 4); P31(32, 4, 1, 4); P31(16, 2, 1, 4); P31(64, 2, 1, 4); P31(8, 2, 1, 4); P31(32, 2, 0, 4); P31(32, 1, 1, 4);
     P31(32, 2, 1, 16); P31(16, 2, 1, 16); P31(8, 2, 1, 16); P31(64, 2, 1, 16); P31(32, 2, 1, 8); P31(32, 2, 1, 2); P31(32, 2, 1, 1); P31(4, 2, 1, 16); P31(2, 2, 1, 16); P31(1, 1, 1, 16); P31(1, 1, 1, 4);
+#define PCP(L_, S_) vs.push_back({"strip 3R:1W R32 C2 buffer ld aux" #L_ " st aux" #S_, [=] { const int g = (W + 4095) / 4096; k_pat31_cpol<32, 2, L_, S_><<<g * ((H + 31) / 32), 256>>>(rgb, out, W, H, g); }, 4.0 * npix})
+    PCP(0, 0); PCP(2, 2); PCP(2, 0); PCP(0, 2); PCP(1, 2); PCP(3, 2); PCP(16, 2); PCP(18, 2); PCP(17, 2); PCP(19, 2); PCP(2, 18); PCP(2, 16); PCP(2, 3); PCP(2, 19); PCP(18, 18);
     // occupancy sensitivity: same strip copy, workgroups per CU limited by a dummy dynamic-LDS allocation
 #define P31L(R_, C_, KB_) vs.push_back({"strip 3R:1W R" #R_ " C" #C_ " nt1 waves/blk4 LDS" #KB_ "KiB", [=] { const int g = (W + 4095) / 4096; k_pat31<R_, C_, 1, 4><<<g * ((H + R_ - 1) / R_), 256, KB_ * 1024>>>(rgb, out, W, H, g); }, 4.0 * npix})
     P31L(32, 2, 20); P31L(32, 2, 26); P31L(32, 2, 32); P31L(32, 2, 40); P31L(32, 2, 53); P31L(32, 2, 80); P31L(32, 4, 53); P31L(32, 6, 53); P31L(32, 4, 80); P31L(32, 8, 80);
