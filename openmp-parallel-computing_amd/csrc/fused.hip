@@ -14,6 +14,7 @@
 #include "sobel_tile.h"
 #include "stream_core.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -50,6 +51,43 @@ __device__ __forceinline__ float luma_f(uint32_t r, uint32_t g, uint32_t b)
 {
     const stream_core::f32x2 y = luma_f2<MODE>(stream_core::f32x2{(float)r, 0.f}, stream_core::f32x2{(float)g, 0.f}, stream_core::f32x2{(float)b, 0.f});
     return y.x;
+}
+
+// One strip row of the fused kernels: this lane's 16 pixels (wv: 48 or 64 interleaved bytes) + the strip-halo pixel
+// of lanes 0 / 63 (hw: R,G,B in bytes 0,1,2) -> luma in f32 -> one step of the rolling Sobel window (rowf2).
+template <int MODE, int CH, int PAR>
+__device__ __forceinline__ uint4 fused_row(stream_core::StateF2 &st, const uint32_t (&wv)[CH * 4], uint32_t hw, int lane, stream_core::f32x2 half2)
+{
+    using namespace stream_core;
+    // pair layout: G[m] = (luma[m-1], luma[m+7]), m = 1..8 from this lane's pixels (m-1, m+7)
+    f32x2 G[10];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x2 r2, g2, b2;
+        if (CH == 3) {
+            const int o0 = 3 * m, o1 = 3 * (m + 8);
+            r2 = f32x2{(float)gh_byte(wv[o0 >> 2], o0 & 3), (float)gh_byte(wv[o1 >> 2], o1 & 3)};
+            g2 = f32x2{(float)gh_byte(wv[(o0 + 1) >> 2], (o0 + 1) & 3), (float)gh_byte(wv[(o1 + 1) >> 2], (o1 + 1) & 3)};
+            b2 = f32x2{(float)gh_byte(wv[(o0 + 2) >> 2], (o0 + 2) & 3), (float)gh_byte(wv[(o1 + 2) >> 2], (o1 + 2) & 3)};
+        } else {
+            r2 = f32x2{(float)gh_byte(wv[m], 0), (float)gh_byte(wv[m + 8], 0)};
+            g2 = f32x2{(float)gh_byte(wv[m], 1), (float)gh_byte(wv[m + 8], 1)};
+            b2 = f32x2{(float)gh_byte(wv[m], 2), (float)gh_byte(wv[m + 8], 2)};
+        }
+        G[m + 1] = luma_f2<MODE>(r2, g2, b2);
+    }
+    const float hl = luma_f<MODE>(gh_byte(hw, 0), gh_byte(hw, 1), gh_byte(hw, 2));
+    // strip halo: pixel x-1 is the left lane's pixel 15 (G[8].y), pixel x+16 the right lane's pixel 0 (G[1].x)
+    // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element expression reads
+    //  element 0 of the vector with this hipcc, which silently turned G[8].y into G[8].x)
+    const float own15 = G[8].y, own0 = G[1].x;
+    float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own15), 0x138, 0xf, 0xf, false));
+    float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own0), 0x130, 0xf, 0xf, false));
+    if (lane == 0) pl = hl;
+    if (lane == 63) pr = hl;
+    G[0] = f32x2{pl, G[8].x};        // (p[-1], p[7])
+    G[9] = f32x2{G[1].y, pr};        // (p[8],  p[16])
+    return rowf2<PAR>(st, G, half2);
 }
 
 // R output rows per strip, C rows per load chunk
@@ -136,37 +174,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
 #pragma unroll
             for (int k = 0; k < NV; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
             __builtin_amdgcn_wave_barrier();
-            // pair layout: G[m] = (luma[m-1], luma[m+7]), m = 1..8 from this lane's pixels (m-1, m+7)
-            f32x2 G[10];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                f32x2 r2, g2, b2;
-                if (CH == 3) {
-                    const int o0 = 3 * m, o1 = 3 * (m + 8);
-                    r2 = f32x2{(float)gh_byte(wv[o0 >> 2], o0 & 3), (float)gh_byte(wv[o1 >> 2], o1 & 3)};
-                    g2 = f32x2{(float)gh_byte(wv[(o0 + 1) >> 2], (o0 + 1) & 3), (float)gh_byte(wv[(o1 + 1) >> 2], (o1 + 1) & 3)};
-                    b2 = f32x2{(float)gh_byte(wv[(o0 + 2) >> 2], (o0 + 2) & 3), (float)gh_byte(wv[(o1 + 2) >> 2], (o1 + 2) & 3)};
-                } else {
-                    r2 = f32x2{(float)gh_byte(wv[m], 0), (float)gh_byte(wv[m + 8], 0)};
-                    g2 = f32x2{(float)gh_byte(wv[m], 1), (float)gh_byte(wv[m + 8], 1)};
-                    b2 = f32x2{(float)gh_byte(wv[m], 2), (float)gh_byte(wv[m + 8], 2)};
-                }
-                G[m + 1] = luma_f2<MODE>(r2, g2, b2);
-            }
             // halo pixel bytes: lane 0 -> last pixel of the left chunk, lane 63 -> first pixel of the right chunk
             const uint32_t hw = lane == 0 ? (CH == 3 ? (hq.w >> 8) : hq.w) : hq.x;      // R,G,B in bytes 0,1,2
-            const float hl = luma_f<MODE>(gh_byte(hw, 0), gh_byte(hw, 1), gh_byte(hw, 2));
-            // strip halo: pixel x-1 is the left lane's pixel 15 (G[8].y), pixel x+16 the right lane's pixel 0 (G[1].x)
-            // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element expression reads
-            //  element 0 of the vector with this hipcc, which silently turned G[8].y into G[8].x)
-            const float own15 = G[8].y, own0 = G[1].x;
-            float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own15), 0x138, 0xf, 0xf, false));
-            float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own0), 0x130, 0xf, 0xf, false));
-            if (lane == 0) pl = hl;
-            if (lane == 63) pr = hl;
-            G[0] = f32x2{pl, G[8].x};        // (p[-1], p[7])
-            G[9] = f32x2{G[1].y, pr};        // (p[8],  p[16])
-            uint4 out = (j & 1) ? rowf2<1>(st, G, half2) : rowf2<0>(st, G, half2);
+            uint4 out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
             if (i >= 2 && i < NROWS) {
                 const int y = y0 + i - 2;
                 if (x == 0) out.x &= 0xffffff00u;
@@ -208,6 +218,161 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
     o.z = lum[8] | (lum[9] << 8) | (lum[10] << 16) | (lum[11] << 24);
     o.w = lum[12] | (lum[13] << 8) | (lum[14] << 16) | (lum[15] << 24);
     return o;
+}
+
+
+// ---- LDS-DMA form (RGB8, width >= 1024): rows go HBM -> LDS directly (global_load_lds_dwordx4), D rows deep -----------
+// The register-staged kernel above holds C rows of loads in VGPRs (24 + 8 registers at C = 2) and pays three ds_write per
+// row to de-interleave them.  Here a wave owns a ring of D row slots in LDS; one row = three 1 KiB LDS-DMA pieces + one
+// dword piece carrying the two strip-halo pixels (lanes 0 and 1 fetch the dword left / right of the strip).  The DMA
+// writes lane-linear (piece base + lane * 16), which is exactly the slab image the de-interleaving ds_read_b128 x3 want.
+// hipcc does not count asm memory operations, so the waits are ours: vmcnt is in-order on gfx9, and at the wait for row i
+// the only loads younger than row i's are those of rows i+1 .. i+D-1 (4 instructions each); output stores in between
+// only make the count conservative.  The last strip of a row is shifted left to end at the frame edge (all strips are
+// full; the overlap is recomputed and stored twice with identical bytes), so no lane of a DMA piece is ever masked.
+__device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_slot)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_dword(uint32_t lds_dst, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_dst)
+                 : "memory");
+}
+// Band plan of a strip kernel launch: level l has n[l] bands of R[l] rows starting at row y[l]; the last level runs to the
+// end of the frame.  Workgroups are dispatched in blockIdx order, so the short bands of the last levels are the ones still
+// running when the grid drains.
+struct BandPlan {
+    int n[2];
+    int R[3];
+    int y[3];
+    int bands;      // total
+};
+inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
+{
+    BandPlan p{};
+    const int full0 = (rows + R0 - 1) / R0;
+    if (n0 < 0 || n0 >= full0 || R1 <= 0) {        // single level
+        p.n[0] = full0; p.n[1] = 0; p.R[0] = p.R[1] = p.R[2] = R0; p.y[0] = 0; p.y[1] = p.y[2] = full0 * R0; p.bands = full0;
+        return p;
+    }
+    p.R[0] = R0; p.n[0] = n0; p.y[0] = 0; p.y[1] = n0 * R0; p.R[1] = R1;
+    const int left1 = rows - p.y[1], full1 = (left1 + R1 - 1) / R1;
+    if (n1 < 0 || n1 >= full1 || R2 <= 0) { p.n[1] = full1; p.R[2] = R1; p.y[2] = p.y[1] + full1 * R1; p.bands = n0 + full1; return p; }
+    p.n[1] = n1; p.y[2] = p.y[1] + n1 * R1; p.R[2] = R2;
+    const int left2 = rows - p.y[2];
+    p.bands = n0 + n1 + (left2 + R2 - 1) / R2;
+    return p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MODE, int D, int SP>
+__global__ __launch_bounds__(stream_core::BLOCK)
+void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
+                 int zero_bot)
+{
+    using namespace stream_core;
+    constexpr int SLOT = STRIP_PX * 3 + 16;                      // one strip row + the halo dword pair
+    constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
+    static_assert(5 * (D - 1) <= 60, "vmcnt is 6 bits");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
+    if (xw >= w) return;
+    if (xw + STRIP_PX > w) xw = w - STRIP_PX;                    // last strip: shifted left, overlaps its neighbour
+    const int x = xw + 16 * lane;
+    // band plan: n[0] bands of R[0] rows, then n[1] of R[1], then bands of R[2] (shorter bands last: a short drain)
+    int R = plan.R[0], y0 = gy_i * plan.R[0];
+    if (gy_i >= plan.n[0]) {
+        const int g1 = gy_i - plan.n[0];
+        R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
+        if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
+    }
+    const int nrows = min(R, rows - y0) + 2;                     // input rows of this band (clipped to the frame) incl. halo
+    const int nch = (nrows + CHK - 1) / CHK;
+    const f32x2 half2 = half2_reg();
+    const uint32_t voff = (uint32_t)xw * 3u + (uint32_t)lane * 16u;            // byte offset of this lane's piece in a row
+    // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its bytes 1..3),
+    //              lane 1 -> the 4 bytes after the strip's last byte (pixel xw+1024 = its bytes 0..2); clamped when outside
+    uint32_t hoff = lane == 0 ? (uint32_t)xw * 3u - 4u : (uint32_t)(xw + STRIP_PX) * 3u;
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + STRIP_PX >= w)) hoff = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+
+    StateF2 st;
+    st.clear();
+
+    auto issue_row = [&](int i, int slot) {
+        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const uint64_t ra = (uint64_t)(uintptr_t)(rgb + (ptrdiff_t)yy * w * 3);
+        const uint8_t *rowb = reinterpret_cast<const uint8_t *>(
+            (uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ra)));
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)slot * SLOT));
+        glds_row3k(dst, rowb, voff);
+        if (lane < 2) glds_dword(dst + STRIP_PX * 3, rowb, hoff);
+    };
+    // nrows >= 3 > D - 1 for D <= 3; for deeper rings the prologue may run past a very short band: clamp_row keeps it readable
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue_row(i, i);
+
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        // steady state: every one of the last D-1 iterations also issued its output store, so D-1 more operations are
+        // younger than row i's loads (before that, and always safe, only the loads are counted)
+        const bool steady = ch >= 2;
+#pragma unroll
+        for (int j = 0; j < CHK; ++j) {
+            const int i = ch * CHK + j;
+            if (i < nrows) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
+                if (i + D - 1 < nrows) {
+                    issue_row(i + D - 1, (j + D - 1) % D);
+                    if (steady) wait_vm<5 * (D - 1)>(); else wait_vm<4 * (D - 1)>();
+                } else {
+                    wait_vm<0>();
+                }
+                const uint8_t *slotp = &ring[wave][j % D][0];
+                const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 48 * lane);
+                const uint4 u0 = sr[0], u1 = sr[1], u2 = sr[2];
+                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * 3);
+                const uint32_t wv[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
+                const uint32_t hw = lane == 0 ? (hh.x >> 8) : hh.y;
+                uint4 out;
+                if (SP >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[11]);   // probe: no compute
+                else out = (j & 1) ? fused_row<MODE, 3, 1>(st, wv, hw, lane, half2) : fused_row<MODE, 3, 0>(st, wv, hw, lane, half2);
+                if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
+                    const int y = y0 + i - 2;
+                    if (x == 0) out.x &= 0xffffff00u;
+                    if (x + 15 == w - 1) out.w &= 0x00ffffffu;
+                    if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+                    store_strip_p<SP % 10>(edge + (size_t)y * w + xw, lane, out);
+                }
+            }
+        }
+    }
 }
 
 template <int MODE, int CH>
@@ -253,7 +418,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
     static const bool use_tile = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
     if (!use_tile) {
-        static const int variant = [] { const char *e = getenv("GH_FUSED_VARIANT"); return e ? atoi(e) : 0; }();   // tuning knob
+        const int variant = GH_TUNE_INT("GH_FUSED_VARIANT", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (width + span - 1) / span;
         const unsigned b = stream_core::BLOCK;
@@ -271,6 +436,32 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             }                                                                                                             \
         } while (0)
         // strip height: taller strips re-read fewer halo rows (2 per strip) but a shard must still fill the 256 CUs
+        const int dma = GH_TUNE_INT("GH_FUSED_DMA", 3);    // ring depth D (0 = off)
+        if (dma && channels == 3 && width >= stream_core::STRIP_PX) {
+            int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
+            if (rd <= 0) {   // band height: taller bands re-read fewer halo rows, but the launch must still fill the 256 CUs
+                const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+                rd = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);
+            }
+            const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // output store policy: 0 default, 1 sc1, 2 nt
+            const int R_ = rd > 0 ? rd : 64;
+            // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
+            const BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
+                                                 GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
+            GH_REQUIRE((long long)groups_x * plan.bands < (1ll << 31), "frame too large for one launch");
+            const unsigned g = (unsigned)((long long)groups_x * plan.bands);
+#define GH_FD(D_, W_)                                                                                                      \
+            do {                                                                                                           \
+                if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
+                else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
+            } while (0)
+            if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }
+            else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else GH_FD(2, 2); }
+            else { if (sp == 0) GH_FD(3, 0); else if (sp == 1) GH_FD(3, 1); else if (sp == 10) GH_FD(3, 10); else if (sp == 12) GH_FD(3, 12); else GH_FD(3, 2); }
+#undef GH_FD
+            GH_LAUNCH_CHECK();
+            return GH_OK;
+        }
         int pick = variant;
         if (pick == 0) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);

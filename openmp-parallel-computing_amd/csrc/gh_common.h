@@ -85,4 +85,20 @@ __device__ __forceinline__ uint32_t gh_sobel_mag(int m)
     return r > 255u ? 255u : r;
 }
 
+
+// Tuning knobs (environment variables): read once per process; with GH_TUNE_DYNAMIC set they are re-read on every
+// launch so that an A/B tool (tools/ab_fused.py) can interleave variants inside one process.
+#include <cstdlib>
+inline int gh_env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+inline bool gh_tune_dynamic()
+{
+    static const bool d = getenv("GH_TUNE_DYNAMIC") != nullptr;
+    return d;
+}
+#define GH_TUNE_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return gh_tune_dynamic() ? gh_env_int(name, dflt) : v_; }())
+
 #endif  // __HIPCC__

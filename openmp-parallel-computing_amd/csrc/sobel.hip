@@ -202,7 +202,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
     if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst) && !use_tile) {
         static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
-        static const int r_env = [] { const char *e = getenv("GH_SOBEL_R"); return e ? atoi(e) : 0; }();   // tuning knob
+        const int r_env = GH_TUNE_INT("GH_SOBEL_R", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (width + span - 1) / span;
         // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 64)

@@ -190,6 +190,7 @@ __device__ __forceinline__ uint4 rowf2(StateF2 &st, const f32x2 (&G)[10], f32x2 
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+
 // opaque(): stops the optimiser from proving a float is a small integer and rewriting the f32 adds as integer/SDWA ops
 __device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
 
@@ -255,19 +256,21 @@ __device__ __forceinline__ void wave_store_rgb48(uint8_t *slab, uint4 *p, int la
 #ifndef GH_STRIP_STORE_POLICY
 #define GH_STRIP_STORE_POLICY 2
 #endif
-__device__ __forceinline__ void store_strip(uint8_t *wave_row /* wave-uniform: first byte of this wave's 1 KiB piece */, int lane, const uint4 v)
+template <int POLICY>
+__device__ __forceinline__ void store_strip_p(uint8_t *wave_row /* wave-uniform: first byte of this wave's 1 KiB piece */, int lane, const uint4 v)
 {
-#if GH_STRIP_STORE_POLICY == 1
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wave_row, 0, STRIP_PX, 0x00020000);
-    u32x4 t;
-    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 16 /* sc1 */);
-#elif GH_STRIP_STORE_POLICY == 2
-    store_stream(reinterpret_cast<uint4 *>(wave_row) + lane, v);
-#else
-    reinterpret_cast<uint4 *>(wave_row)[lane] = v;
-#endif
+    if (POLICY == 1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wave_row, 0, STRIP_PX, 0x00020000);
+        u32x4 t;
+        t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 16 /* sc1 */);
+    } else if (POLICY == 2) {
+        store_stream(reinterpret_cast<uint4 *>(wave_row) + lane, v);
+    } else {
+        reinterpret_cast<uint4 *>(wave_row)[lane] = v;
+    }
 }
+__device__ __forceinline__ void store_strip(uint8_t *wave_row, int lane, const uint4 v) { store_strip_p<GH_STRIP_STORE_POLICY>(wave_row, lane, v); }
 
 // 0.5f kept in a VGPR (opaque to the optimiser) so the fma above can take it as a register operand
 __device__ __forceinline__ float half_reg()

@@ -7,7 +7,12 @@ import os
 import sys
 
 import numpy as np
+import os
+
 import pytest
+
+# the HIP library re-reads its tuning knobs on every launch (tests sweep kernel variants in one process)
+os.environ.setdefault("GH_TUNE_DYNAMIC", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

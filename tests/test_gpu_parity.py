@@ -182,7 +182,8 @@ def test_row_bands_equal_whole_frame(pkg, oracle, torch_mod, w, h, parts):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("w,h,ch", [(1024, 40, 3), (2064, 35, 3), (64, 5, 4), (16, 3, 3), (4096, 33, 4)])
+@pytest.mark.parametrize("w,h,ch", [(1024, 40, 3), (2064, 35, 3), (64, 5, 4), (16, 3, 3), (4096, 33, 4), (1040, 3, 3), (3072, 1, 3),
+                                    (1024, 2, 3), (4112, 70, 3), (5136, 131, 3)])
 def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
     img = oracle.frame_rand(w, h, ch, seed=w ^ h)
     d = dev(torch_mod, img)
@@ -204,6 +205,22 @@ def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
                 buf[rows + 1] = d[y1]
             pkg.hostapi.gray_sobel_fused_rows(buf, got[y0:y1], rows, 0, y0 == 0, y1 == h)
         assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("knobs", [{"GH_FUSED_DMA": "0"}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "4"}, {"GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "16"},
+                                   {"GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "64", "GH_FUSED_DMA_N0": "1", "GH_FUSED_DMA_R1": "32", "GH_FUSED_DMA_N1": "1",
+                                    "GH_FUSED_DMA_R2": "16"}, {"GH_FUSED_DMA": "0", "GH_FUSED_VARIANT": "1"}])
+def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
+    """Every tuning variant of the fused kernel (register-staged, LDS-DMA ring depths, band plans) is bit-exact too.
+    tests/conftest.py sets GH_TUNE_DYNAMIC so that the library re-reads the knobs on every launch."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for (w, h) in ((2064, 150), (1024, 67), (4096, 3)):
+        img = oracle.frame_rand(w, h, 3, seed=w + h)
+        d = dev(torch_mod, img)
+        for mode in (0, 1):
+            want = oracle.sobel(oracle.gray_to_plane(img, mode))
+            assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), (knobs, w, h, mode)
 
 
 # ---- the reference's drivers and historic kernels -----------------------------------------------

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of one C-ABI kernel under several tuning-knob settings, inside one process (developer tool).
+
+usage: ab_fused.py [--op fused|sobel|gray] [--w W] [--h H] [--rounds N] "NAME=K1:V1,K2:V2" ...
+Each variant is a set of environment knobs (GH_TUNE_DYNAMIC makes the library re-read them per launch).
+"""
+import argparse, importlib, os, sys, hashlib, statistics
+os.environ["GH_TUNE_DYNAMIC"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ap = argparse.ArgumentParser()
+ap.add_argument("--op", default="fused"); ap.add_argument("--w", type=int, default=16384); ap.add_argument("--h", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=9); ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("variants", nargs="*")
+a = ap.parse_args()
+W, H = a.w, (a.h or a.w)
+pkg = importlib.import_module("openmp-parallel-computing_amd"); api = pkg.hostapi; api.init(0)
+torch.manual_seed(1)
+rgb = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda")
+plane = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda")
+out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (lambda: api.sobel(plane, out=out), 2),
+       "gray": (lambda: api.gray_to_plane(rgb, 0, out=out), 4)}
+fn, bpp = ops[a.op]
+variants = [("base", {})]
+for v in a.variants:
+    name, _, kv = v.partition("=")
+    variants.append((name, dict(x.split(":") for x in kv.split(",") if x)))
+allkeys = {k for _, d in variants for k in d}
+def setenv(d):
+    for k in allkeys: os.environ.pop(k, None)
+    os.environ.update(d)
+times = {n: [] for n, _ in variants}; shas = {}
+for rnd in range(a.rounds + 1):
+    for n, d in variants:
+        setenv(d)
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); [fn() for _ in range(a.reps)]; e1.record(); e1.synchronize()
+        if rnd: times[n].append(e0.elapsed_time(e1) / a.reps)
+        else: shas[n] = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"{a.op} {W}x{H}, {a.rounds} interleaved rounds x {a.reps} launches")
+for n, _ in variants:
+    t = times[n]; med = statistics.median(t)
+    print(f"{n:28s} med {med:.4f} ms  min {min(t):.4f}  max {max(t):.4f}  {bpp*W*H/med/1e6:7.0f} GB/s  {bpp*W*H/med/8e7:5.1f}%  sha {shas[n]}")
