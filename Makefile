@@ -18,7 +18,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: the IEEE luma model needs un-fused mul/add (FMA mode calls fmaf explicitly).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
-HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/streamed.hip $(CSRC)/shim.hip
+HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/streamed.hip $(CSRC)/comm.hip $(CSRC)/shim.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h $(CSRC)/stream_core.h
 
@@ -34,7 +34,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 
 $(LIB): $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -ldl -o $@
 
 CLI_COMMON := $(CSRC)/cli/image_io.cpp $(CSRC)/cli/jpeg_decode.cpp
 cli: bin/grayscale bin/grayscale_sobel bin/gh_imgtool

@@ -53,6 +53,10 @@ def parse_args():
                     help="strong: the 16384^2 frame is row-sharded over N GPUs; weak: every GPU gets `height` rows")
     ap.add_argument("--mode", choices=["ieee", "fma"], default="ieee")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the halo exchange with interior rows")
+    ap.add_argument("--exchange", choices=["native", "torch"], default=os.environ.get("GH_BENCH_EXCHANGE", "native"),
+                    help="N > 1: halo exchange + shard launches issued by libgrayhip's own RCCL communicator from C++ (native) "
+                         "or by torch.distributed P2P ops from Python (torch); native falls back to torch if it cannot be set up "
+                         "or disagrees with it on the first frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel measurements after the timed region")
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
@@ -64,7 +68,7 @@ def measured_traffic(kernel_name: str, px: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction), scaled to this launch's
     pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself."""
-    sym = {"gray_sobel_fused_rgb8": "k_fused_stream", "gray_rgb8_to_plane": "k_gray_rgb_to_plane_w", "sobel3x3_u8": "k_sobel_stream"}
+    sym = {"gray_sobel_fused_rgb8": "k_fused_dma", "gray_rgb8_to_plane": "k_gray_rgb_to_plane_w", "sobel3x3_u8": "k_sobel_stream"}
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic.json")), key=os.path.getmtime, reverse=True):
@@ -151,11 +155,20 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         return 1
+    # GH_BENCH_REHEARSAL=1: several ranks share the GPUs that are present (a one-GPU box), process group over gloo.
+    # Only for exercising the multi-rank code path; RCCL refuses two ranks on one device, so the exchange falls back
+    # to torch.distributed P2P (through host memory) and the numbers mean nothing.
+    rehearsal = os.environ.get("GH_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     pkg = importlib.import_module("openmp-parallel-computing_amd")
     api, sharding = pkg.hostapi, pkg.sharding
@@ -171,16 +184,60 @@ def main() -> int:
     overlap = not args.no_overlap
     backend = sharding.HipBackend(mode)
 
+    def all_ranks_agree(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # N > 1: who issues the halo exchange.  native = libgrayhip's own RCCL communicator, whole step in one C++ call.
+    native, exchange, exchange_note = None, "none", ""
+    if world > 1:
+        exchange = "torch.distributed P2P (batch_isend_irecv over RCCL)"
+        if args.exchange == "native":
+            try:
+                native = sharding.NativeHaloComm(rank, world)
+            except Exception as exc:
+                exchange_note = f"native communicator unavailable on rank {rank}: {exc}"
+            if not all_ranks_agree(native is not None):
+                native = None
+
+    def make_runner(native_comm):
+        if fused:
+            return sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap, native_comm=native_comm)
+        return sharding.ShardedGraySobel(geom, backend, device, overlap=overlap, native_comm=native_comm)
+
     # synthetic frame shard, resident in HBM before the timed region
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
+    frame = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
+    runner = make_runner(native)
     if fused:
-        runner = sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap)
-        runner.shard.copy_(torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen))
+        runner.shard.copy_(frame)
         rgb = runner.shard
+        del frame
     else:
-        runner = sharding.ShardedGraySobel(geom, backend, device, overlap=overlap)
-        rgb = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
+        rgb = frame
+    run_once = (lambda r: r.step()) if fused else (lambda r: r.step(rgb))
+    if native is not None:
+        # first frame through both exchange paths: the C++ path must reproduce the torch.distributed one bit for bit
+        ref_runner = make_runner(None)
+        if fused:
+            ref_runner.shard.copy_(rgb)
+        try:
+            run_once(ref_runner)
+            run_once(runner)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref_runner.edge, runner.edge))
+        except Exception as exc:
+            same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
+        if all_ranks_agree(same):
+            exchange = "libgrayhip RCCL communicator (ncclSend/ncclRecv group + shard launches issued from C++, csrc/comm.hip)"
+            del ref_runner
+        else:
+            exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frame; using torch"
+            runner, native = ref_runner, None
+            rgb = runner.shard if fused else rgb
+        torch.cuda.empty_cache()
     edge = runner.edge
 
     stream = torch.cuda.current_stream()
@@ -215,6 +272,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    host_enqueue = time.perf_counter() - t0       # host time to issue the steps (GPU still running)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -232,6 +290,25 @@ def main() -> int:
         timed_kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
         timed_kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
 
+    # N > 1: every rank's halo rows must hold its neighbours' edge rows (what the last step's exchange delivered)
+    halo_ok = True
+    if world > 1:
+        firsts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+        lasts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(firsts, rgb[0].contiguous())
+        dist.all_gather(lasts, rgb[rows - 1].contiguous())
+        if fused:
+            up_row, down_row = runner.rgb[0], runner.rgb[rows + 1]
+            conv = lambda t: t
+        else:
+            up_row, down_row = runner.luma[0], runner.luma[rows + 1]
+            conv = lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W)
+        if rank > 0:
+            halo_ok &= bool(torch.equal(up_row, conv(lasts[rank - 1])))
+        if rank < world - 1:
+            halo_ok &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
+        halo_ok = all_ranks_agree(halo_ok)
+
     # parity spot check of what was just timed (checker only; not in the timed region)
     check = "skipped"
     if not args.no_check and rank == 0:
@@ -242,11 +319,17 @@ def main() -> int:
             src = rgb[0:r + 1].cpu().numpy()
             want = O.sobel(O.gray_to_plane(src, mode))[: r - 1]
             got = edge[: r - 1].cpu().numpy()
-            check = "ok" if np.array_equal(got[1:], want[1:]) and not got[0].any() else "MISMATCH"
+            good = np.array_equal(got[1:], want[1:]) and not got[0].any()
+            if world > 1 and fused and rows > 40:
+                # the shard's last rows, which depend on the halo row received from rank 1
+                src = runner.rgb[rows - 30:rows + 2].cpu().numpy()          # buffer rows = shard rows rows-31 .. rows-1 + the halo row
+                want = O.sobel(O.gray_to_plane(src, mode))[1:-1]             # shard rows rows-30 .. rows-1
+                good = good and np.array_equal(edge[rows - 30:rows].cpu().numpy(), want)
+            check = "ok" if good else "MISMATCH"
         except Exception as exc:  # the checker is optional on the GPU box; a mismatch is never hidden
             check = f"unavailable ({type(exc).__name__})"
-        if check == "MISMATCH":
-            print("bench.py: parity spot check FAILED", file=sys.stderr)
+        if check == "MISMATCH" or not halo_ok:
+            print(f"bench.py: parity spot check FAILED (check={check}, halo rows ok={halo_ok})", file=sys.stderr)
             return 3
 
     # per-kernel table (outside the timed region): every kernel of the hot path on this rank's shard
@@ -301,7 +384,7 @@ def main() -> int:
             roofline = {"bound": "hbm", "kernel": ("gray_sobel_fused_rgb8" if fused else "gray_rgb8_to_plane+sobel3x3_u8")
                         + " (per rank, incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None}
-        halo = "an RGB row (fused kernel recomputes halo luma)" if fused else "a luma row"
+        halo = "RGB row (the fused kernel recomputes halo luma)" if fused else "luma row"
         out = {
             "metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel",
             "value": round(value, 1),
@@ -322,12 +405,17 @@ def main() -> int:
                 "parallelism": "single GPU" if world == 1 else
                                f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv"
                                + ("" if args.no_overlap else ", overlapped with the interior rows"),
+                "halo_exchange": exchange + (f" [{exchange_note}]" if exchange_note else ""),
             },
             "roofline": roofline,
             "kernels": kern_table,
             "ms_per_step_events": round(step_ms_events, 4),
             "parity_spot_check": check,
+            "halo_rows_check": "ok" if halo_ok else "MISMATCH",
+            "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1),
         }
+        if rehearsal:
+            out["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(W, min(args.cpu_sample_rows, H_total))

@@ -135,6 +135,36 @@ GH_API int gh_sum_rgb8_host(const unsigned char *rgb, size_t npix, uint64_t sums
 GH_API int gh_gray_sobel_streamed_host(const unsigned char *rgb, unsigned char *edge, int width, int height, int channels,
                                        int mode, int tile_rows, int host_buffers_pinned, double *seconds);
 
+/* ---- row-sharded frames: one process per GPU, halo rows over RCCL (ncclSend/ncclRecv on xGMI) --------------
+ * The reference parallelises rows with OpenMP threads over one shared image (monolithic/src/sobel.c:10,
+ * parallel_to_grayscale.c:7); across GPUs each rank owns a contiguous block of rows and the 3x3 stencil needs the
+ * row above and below the block from the neighbouring ranks.  RCCL is dlopen'ed by gh_comm_init (the rest of the
+ * library does not depend on it).  Bootstrap: rank 0 calls gh_comm_unique_id, the 128 bytes reach the other ranks
+ * by any means (torch.distributed broadcast, a file, MPI), every rank calls gh_comm_init on its own device. */
+#define GH_COMM_ID_BYTES 128
+typedef void *gh_comm_t;
+GH_API int gh_comm_unique_id(uint8_t id[GH_COMM_ID_BYTES]);
+GH_API int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_comm_t *out);
+GH_API int gh_comm_rank(gh_comm_t comm);
+GH_API int gh_comm_world(gh_comm_t comm);
+GH_API int gh_comm_destroy(gh_comm_t comm);
+/* rehearsal hook for a one-GPU box: the sharded steps below treat this rank as a MIDDLE shard whose two neighbours
+ * are itself (ncclSend/ncclRecv to self), i.e. the halo rows become copies of the shard's own first / last row */
+GH_API int gh_comm_set_loopback(gh_comm_t comm, int on);
+/* one ncclGroup on `stream`: send_up -> up_peer and its row -> recv_up; same downwards; peer < 0 = frame border */
+GH_API int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void *recv_up, int down_peer,
+                                const void *send_down, void *recv_down, size_t bytes, gh_stream_t stream);
+/* in-place sum of count u64 over all ranks (channel sums of old/parallel_avg_pixel.c on a sharded frame) */
+GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream);
+/* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  The exchange runs on
+ * the communicator's side stream while the interior rows run on `stream`; the first and last row follow once the
+ * halo has landed.  Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
+ *   fused: buf = interleaved RGB8/RGBA8 rows, the halo is one RGB row (the luma plane never exists in HBM)
+ *   sobel: buf = luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */
+GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
+                                     int mode, gh_stream_t stream);
+GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream);
+
 /* The reference's own symbols (same prototypes as monolithic/include/ headers).  They return void in
  * the reference, so a failure is reported on stderr and the process is aborted -- never a
  * silent CPU fallback.  mode = gh_default_mode(). */

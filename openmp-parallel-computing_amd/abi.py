@@ -50,6 +50,16 @@ SIGNATURES = {
     "gh_pipeline_gray_sobel_host": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gh_sum_rgb8_host": (C.c_int, [_u8p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gh_gray_sobel_streamed_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gh_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_comm_rank": (C.c_int, [C.c_void_p]),
+    "gh_comm_world": (C.c_int, [C.c_void_p]),
+    "gh_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gh_comm_set_loopback": (C.c_int, [C.c_void_p, C.c_int]),
+    "gh_halo_exchange_dev": (C.c_int, [C.c_void_p, C.c_int, _u8p, _u8p, C.c_int, _u8p, _u8p, C.c_size_t, _stream]),
+    "gh_comm_allreduce_sum_u64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
+    "gh_sharded_fused_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "convert_to_grayscale": (None, [_u8p, C.c_int, C.c_int, C.c_int]),
     "sobel_edge": (None, [_u8p, _u8p, C.c_int, C.c_int]),
     "gh_selftest_sobel_mag": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -1,0 +1,244 @@
+// comm.hip -- row-shard halo exchange over RCCL (ncclSend/ncclRecv on xGMI) and the sharded pipeline step, host side.
+//
+// The reference has no distributed layer (OpenMP threads over one shared image, monolithic/src/sobel.c:10-24 and
+// parallel_to_grayscale.c:7-16).  Its row-parallel `#pragma omp parallel for` becomes: one process per GPU, each owning
+// a contiguous block of rows, and one exchange step -- the row above and the row below a shard come from the
+// neighbouring ranks.  At 8 GPUs a 16384^2 frame leaves ~25 us of kernel time per shard, so the
+// host cost of the exchange decides the scaling curve; this file issues the two send/recv pairs as one ncclGroup on a
+// side stream straight from C++ (no Python between the calls) and overlaps them with the interior rows, which do not
+// depend on the halo.
+//
+// RCCL is loaded with dlopen at gh_comm_init time: the single-GPU library, the CLIs and the drop-in boundary do not
+// depend on librccl.so.
+#include "gh_common.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+// the slice of the RCCL API used here (rccl.h: ncclGetUniqueId / ncclCommInitRank / ncclSend / ncclRecv / ...)
+constexpr int kIdBytes = 128;
+struct NcclId { char internal[kIdBytes]; };
+using nccl_comm_t = void *;
+enum { kNcclUint8 = 1, kNcclUint64 = 5, kNcclSum = 0 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+char g_rccl_err[256];
+
+void load_rccl()
+{
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_rccl.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.so) break;
+    }
+    if (!g_rccl.so) {
+        snprintf(g_rccl_err, sizeof g_rccl_err, "cannot load librccl.so: %s", dlerror());
+        return;
+    }
+#define GH_SYM(field, name)                                                                          \
+    do {                                                                                             \
+        *reinterpret_cast<void **>(&g_rccl.field) = dlsym(g_rccl.so, name);                          \
+        if (!g_rccl.field) { snprintf(g_rccl_err, sizeof g_rccl_err, "librccl.so lacks %s", name); g_rccl.so = nullptr; return; }  \
+    } while (0)
+    GH_SYM(GetUniqueId, "ncclGetUniqueId");
+    GH_SYM(CommInitRank, "ncclCommInitRank");
+    GH_SYM(CommDestroy, "ncclCommDestroy");
+    GH_SYM(GroupStart, "ncclGroupStart");
+    GH_SYM(GroupEnd, "ncclGroupEnd");
+    GH_SYM(Send, "ncclSend");
+    GH_SYM(Recv, "ncclRecv");
+    GH_SYM(AllReduce, "ncclAllReduce");
+    GH_SYM(GetErrorString, "ncclGetErrorString");
+#undef GH_SYM
+}
+
+int need_rccl()
+{
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl.so) return gh_set_error(GH_ERR_HIP, "RCCL unavailable: %s", g_rccl_err);
+    return GH_OK;
+}
+
+#define GH_NCCL_TRY(expr)                                                                               \
+    do {                                                                                                \
+        const int r_ = (expr);                                                                          \
+        if (r_ != 0) return gh_set_error(GH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__);  \
+    } while (0)
+
+struct Comm {
+    nccl_comm_t nccl = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t side = nullptr;          // the exchange runs here, beside the interior rows on the caller's stream
+    hipEvent_t ready = nullptr, landed = nullptr;
+    bool loopback = false;               // rehearsal on one GPU: both neighbours are this rank (ncclSend/ncclRecv to self)
+};
+
+}  // namespace
+
+extern "C" {
+
+int gh_comm_unique_id(uint8_t id[GH_COMM_ID_BYTES])
+{
+    GH_REQUIRE(id, "null id");
+    static_assert(GH_COMM_ID_BYTES == kIdBytes, "ncclUniqueId is 128 bytes");
+    if (int rc = need_rccl()) return rc;
+    NcclId nid;
+    GH_NCCL_TRY(g_rccl.GetUniqueId(&nid));
+    memcpy(id, nid.internal, kIdBytes);
+    return GH_OK;
+}
+
+int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_comm_t *out)
+{
+    GH_REQUIRE(id && out, "null pointer");
+    GH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    if (int rc = gh_ensure_init()) return rc;
+    if (int rc = need_rccl()) return rc;
+    Comm *c = new Comm;
+    c->rank = rank;
+    c->world = world;
+    NcclId nid;
+    memcpy(nid.internal, id, kIdBytes);
+    const int r = g_rccl.CommInitRank(&c->nccl, world, nid, rank);
+    if (r != 0) {
+        delete c;
+        return gh_set_error(GH_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+    }
+    GH_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
+    *out = c;
+    return GH_OK;
+}
+
+int gh_comm_rank(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->rank : -1; }
+int gh_comm_world(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->world : -1; }
+
+int gh_comm_set_loopback(gh_comm_t comm, int on)
+{
+    GH_REQUIRE(comm, "null communicator");
+    static_cast<Comm *>(comm)->loopback = on != 0;
+    return GH_OK;
+}
+
+int gh_comm_destroy(gh_comm_t comm)
+{
+    if (!comm) return GH_OK;
+    Comm *c = static_cast<Comm *>(comm);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->landed) (void)hipEventDestroy(c->landed);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+    return GH_OK;
+}
+
+// One ncclGroup: my `send_up` row goes to up_peer and its row arrives in recv_up; likewise downwards.  A peer < 0 means
+// "no neighbour on that side" (frame border).  Everything is enqueued on `stream`.
+int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void *recv_up, int down_peer, const void *send_down,
+                         void *recv_down, size_t bytes, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    Comm *c = static_cast<Comm *>(comm);
+    GH_REQUIRE(up_peer < c->world && down_peer < c->world, "peer out of range");
+    if (bytes == 0 || (up_peer < 0 && down_peer < 0)) return GH_OK;
+    GH_REQUIRE((up_peer < 0 || (send_up && recv_up)) && (down_peer < 0 || (send_down && recv_down)), "null halo row");
+    hipStream_t s = (hipStream_t)stream;
+    GH_NCCL_TRY(g_rccl.GroupStart());
+    int r = 0;
+    if (up_peer >= 0) {
+        r |= g_rccl.Send(send_up, bytes, kNcclUint8, up_peer, c->nccl, s);
+        r |= g_rccl.Recv(recv_up, bytes, kNcclUint8, up_peer, c->nccl, s);
+    }
+    if (down_peer >= 0) {
+        r |= g_rccl.Send(send_down, bytes, kNcclUint8, down_peer, c->nccl, s);
+        r |= g_rccl.Recv(recv_down, bytes, kNcclUint8, down_peer, c->nccl, s);
+    }
+    const int e = g_rccl.GroupEnd();
+    if (r != 0 || e != 0) return gh_set_error(GH_ERR_HIP, "halo exchange failed: %s", g_rccl.GetErrorString(r ? r : e));
+    return GH_OK;
+}
+
+int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream)
+{
+    GH_REQUIRE(comm && buf_dev, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    GH_NCCL_TRY(g_rccl.AllReduce(buf_dev, buf_dev, count, kNcclUint64, kNcclSum, c->nccl, (hipStream_t)stream));
+    return GH_OK;
+}
+
+}  // extern "C"
+
+// ---- one pipeline step of a row shard ------------------------------------------------------------------------------
+// buf: (rows + 2) rows of `row_bytes`; rows 1..rows are the shard, rows 0 / rows+1 receive the neighbours' edge rows.
+// exchange (side stream) || interior rows (caller's stream) -> first and last row once the halo has landed.
+template <typename Launch>
+static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */)
+{
+    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback) up = down = c->rank;      // a middle shard whose neighbours are itself: halo = its own edge rows
+    if (up < 0 && down < 0) return launch(0, rows, 1, 1);
+    // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
+    GH_HIP_TRY(hipEventRecord(c->ready, s));
+    GH_HIP_TRY(hipStreamWaitEvent(c->side, c->ready, 0));
+    if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
+                                      row_bytes, c->side))
+        return rc;
+    GH_HIP_TRY(hipEventRecord(c->landed, c->side));
+    if (rows >= 3) {
+        if (int rc = launch(1, rows - 2, 0, 0)) return rc;                       // interior: local rows only
+        GH_HIP_TRY(hipStreamWaitEvent(s, c->landed, 0));
+        if (int rc = launch(0, 1, up < 0, 0)) return rc;
+        return launch(rows - 1, 1, 0, down < 0);
+    }
+    GH_HIP_TRY(hipStreamWaitEvent(s, c->landed, 0));
+    return launch(0, rows, up < 0, down < 0);
+}
+
+extern "C" {
+
+int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(rgb_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width * channels;
+    return sharded_step(c, rgb_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
+        return gh_gray_sobel_fused_rows_dev(rgb_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, channels, mode, tb, bb, stream);
+    });
+}
+
+int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(luma_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width;
+    return sharded_step(c, luma_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
+        return gh_sobel_u8_rows_dev(luma_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, tb, bb, stream);
+    });
+}
+
+}  // extern "C"

@@ -84,6 +84,69 @@ class HipBackend:
         return lambda: chk(fn(src, dst, h * w, c, mode, torch.cuda.current_stream().cuda_stream), "gray_to_plane")
 
 
+class NativeHaloComm:
+    """RCCL communicator owned by libgrayhip (csrc/comm.hip): the halo exchange and the whole sharded step are issued
+    from C++, one ctypes call per step, instead of torch.distributed P2P ops (~100 us of host time per step, which at
+    8 GPUs is several times the shard's kernel time).  torch.distributed is used once, to broadcast the 128-byte
+    ncclUniqueId; `group` may be any initialised process group (nccl or gloo)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank: int, world: int, group=None):
+        import ctypes as C
+        from . import abi
+        self.abi, self.lib = abi, abi.load()
+        self.rank, self.world = rank, world
+        ident = (C.c_uint8 * self.ID_BYTES)()
+        if rank == 0:
+            abi.check(self.lib.gh_comm_unique_id(ident), "gh_comm_unique_id")
+        if world > 1:
+            import torch.distributed as dist
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(box[0])
+        handle = C.c_void_p()
+        abi.check(self.lib.gh_comm_init(ident, rank, world, C.byref(handle)), "gh_comm_init")
+        self.handle = handle
+
+    def set_loopback(self, on: bool = True):
+        """One-GPU rehearsal: both neighbours of the sharded steps are this rank (see gh_comm_set_loopback)."""
+        self.abi.check(self.lib.gh_comm_set_loopback(self.handle, int(on)), "gh_comm_set_loopback")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gh_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def halo_exchange(self, up_peer, send_up, recv_up, down_peer, send_down, recv_down, nbytes, stream):
+        p = lambda t: 0 if t is None else t.data_ptr()
+        self.abi.check(self.lib.gh_halo_exchange_dev(self.handle, up_peer, p(send_up), p(recv_up), down_peer, p(send_down), p(recv_down),
+                                                     nbytes, stream), "gh_halo_exchange_dev")
+
+    def allreduce_sum_u64(self, t, stream):
+        self.abi.check(self.lib.gh_comm_allreduce_sum_u64_dev(self.handle, t.data_ptr(), t.numel(), stream), "gh_comm_allreduce_sum_u64_dev")
+
+    def bind_fused_step(self, rgb_buf, edge, rows, mode):
+        import torch
+        w, c = rgb_buf.shape[1], rgb_buf.shape[2]
+        assert rgb_buf.shape[0] == rows + 2 and tuple(edge.shape) == (rows, w) and rgb_buf.is_contiguous() and edge.is_contiguous()
+        fn, chk, h, src, dst = self.lib.gh_sharded_fused_step_dev, self.abi.check, self.handle, rgb_buf.data_ptr(), edge.data_ptr()
+        return lambda: chk(fn(h, src, dst, w, rows, c, mode, torch.cuda.current_stream().cuda_stream), "gh_sharded_fused_step_dev")
+
+    def bind_sobel_step(self, luma_buf, edge, rows):
+        import torch
+        w = luma_buf.shape[1]
+        assert luma_buf.shape[0] == rows + 2 and tuple(edge.shape) == (rows, w) and luma_buf.is_contiguous() and edge.is_contiguous()
+        fn, chk, h, src, dst = self.lib.gh_sharded_sobel_step_dev, self.abi.check, self.handle, luma_buf.data_ptr(), edge.data_ptr()
+        return lambda: chk(fn(h, src, dst, w, rows, torch.cuda.current_stream().cuda_stream), "gh_sharded_sobel_step_dev")
+
+
 def _bind(backend, name, generic, *args):
     """Use the backend's pre-bound launcher when it has one (HipBackend), else wrap the generic call."""
     binder = getattr(backend, "bind_" + name, None)
@@ -120,7 +183,7 @@ class ShardedGraySobel:
     (rows, width).  step(rgb_shard) enqueues everything asynchronously and returns `edge`.
     """
 
-    def __init__(self, geom: ShardGeometry, backend, device, group=None, overlap: bool = True):
+    def __init__(self, geom: ShardGeometry, backend, device, group=None, overlap: bool = True, native_comm=None):
         import torch
         self.g = geom
         self.backend = backend
@@ -131,8 +194,13 @@ class ShardedGraySobel:
         self.edge = torch.empty((rows, geom.width), dtype=torch.uint8, device=device)
         self._ops = None
         self._gray_for = None          # (data_ptr of the last rgb shard, bound launcher)
+        self._native = None            # exchange + Sobel launches issued by libgrayhip itself (NativeHaloComm)
         b, g = backend, geom
         if rows == 0:
+            return
+        if native_comm is not None and g.world > 1:
+            assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
+            self._native = native_comm.bind_sobel_step(self.luma, self.edge, rows)
             return
         if g.world == 1:
             self._whole = _bind(b, "sobel_rows", b.sobel_rows, self.luma, self.edge, rows, True, True)
@@ -170,6 +238,9 @@ class ShardedGraySobel:
             self._gray_for = (rgb_shard.data_ptr(),
                               _bind(self.backend, "gray_to_plane", self.backend.gray_to_plane, rgb_shard, self.luma[1:rows + 1]))
         self._gray_for[1]()
+        if self._native is not None:
+            self._native()
+            return self.edge
         if g.world == 1:
             self._whole()
             return self.edge
@@ -197,7 +268,7 @@ class ShardedFusedGraySobel:
     neighbours' edge rows.  step() enqueues exchange + kernels asynchronously and returns `edge`.
     """
 
-    def __init__(self, geom: ShardGeometry, backend, device, channels: int = 3, group=None, overlap: bool = True):
+    def __init__(self, geom: ShardGeometry, backend, device, channels: int = 3, group=None, overlap: bool = True, native_comm=None):
         import torch
         self.g = geom
         self.backend = backend
@@ -207,8 +278,13 @@ class ShardedFusedGraySobel:
         self.rgb = torch.zeros((rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
         self.edge = torch.empty((rows, geom.width), dtype=torch.uint8, device=device)
         self._ops = None
+        self._native = None            # exchange + fused launches issued by libgrayhip itself (NativeHaloComm)
         b, g = backend, geom
         if rows == 0:
+            return
+        if native_comm is not None and g.world > 1:
+            assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
+            self._native = native_comm.bind_fused_step(self.rgb, self.edge, rows, getattr(backend, "mode", 0))
             return
         if g.world == 1:
             self._whole = _bind(b, "fused_rows", b.fused_rows, self.rgb, self.edge, rows, True, True)
@@ -242,6 +318,9 @@ class ShardedFusedGraySobel:
         import torch.distributed as dist
         g = self.g
         if g.rows == 0:
+            return self.edge
+        if self._native is not None:
+            self._native()
             return self.edge
         if g.world == 1:
             self._whole()

@@ -402,3 +402,68 @@ def test_conv3x3_streaming_path(pkg, oracle, torch_mod, w, h):
     for k, norm in cases:
         got = pkg.hostapi.conv3x3(d, k, norm).cpu().numpy()
         assert np.array_equal(got, oracle.conv3x3(img, k, norm)), (w, h, k, norm)
+
+
+# ---- native RCCL halo exchange (csrc/comm.hip) on one GPU: a world-of-1 communicator, ncclSend/ncclRecv to self --------
+
+@pytest.fixture(scope="module")
+def native_comm(pkg):
+    comm = pkg.sharding.NativeHaloComm(0, 1)
+    yield comm
+    comm.close()
+
+
+def test_native_comm_self_exchange(pkg, native_comm, torch_mod):
+    t = torch_mod
+    a = t.randint(0, 256, (49152,), dtype=t.uint8, device="cuda")
+    b = t.randint(0, 256, (49152,), dtype=t.uint8, device="cuda")
+    ra, rb = t.zeros_like(a), t.zeros_like(b)
+    s = t.cuda.current_stream().cuda_stream
+    native_comm.halo_exchange(0, a, ra, 0, b, rb, a.numel(), s)      # both "neighbours" are this rank
+    t.cuda.synchronize()
+    assert t.equal(ra, a) and t.equal(rb, b)
+    native_comm.halo_exchange(-1, None, None, 0, b, ra, b.numel(), s)   # frame border above, neighbour below
+    t.cuda.synchronize()
+    assert t.equal(ra, b)
+    sums = t.tensor([1, 2, 3], dtype=t.int64, device="cuda")
+    native_comm.allreduce_sum_u64(sums, s)
+    t.cuda.synchronize()
+    assert sums.cpu().tolist() == [1, 2, 3]
+
+
+@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130)])
+def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h):
+    """The C++ sharded step (exchange on the side stream || interior rows, then first / last row) as a middle shard whose
+    neighbours are itself: the halo rows must become copies of the shard's own edge rows, i.e. the result equals the
+    oracle on the frame padded by replicating its first and last row."""
+    t = torch_mod
+    img = oracle.frame_rand(w, h, 3, seed=w * 7 + h)
+    padded = np.concatenate([img[:1], img, img[-1:]], axis=0)
+    want = oracle.sobel(oracle.gray_to_plane(padded, 0))[1:-1]
+    want[:, 0] = 0
+    want[:, -1] = 0
+    native_comm.set_loopback(True)
+    try:
+        geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
+        backend = pkg.sharding.HipBackend(0)
+        # fused: RGB halo rows
+        buf = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+        buf[1:h + 1] = dev(t, img)
+        edge = t.full((h, w), 7, dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_step(buf, edge, h, 0)
+        for _ in range(3):              # repeated steps: the exchange of step k+1 must wait for step k's edge rows
+            step()
+        t.cuda.synchronize()
+        assert np.array_equal(buf[0].cpu().numpy(), img[0]) and np.array_equal(buf[h + 1].cpu().numpy(), img[-1])
+        assert np.array_equal(edge.cpu().numpy(), want)
+        # split: luma halo rows
+        luma = t.zeros((h + 2, w), dtype=t.uint8, device="cuda")
+        backend.gray_to_plane(dev(t, img), luma[1:h + 1])
+        edge2 = t.full((h, w), 9, dtype=t.uint8, device="cuda")
+        step2 = native_comm.bind_sobel_step(luma, edge2, h)
+        step2(); step2()
+        t.cuda.synchronize()
+        assert np.array_equal(edge2.cpu().numpy(), want)
+        del geom
+    finally:
+        native_comm.set_loopback(False)
