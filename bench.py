@@ -158,7 +158,10 @@ def main() -> int:
     # GH_BENCH_REHEARSAL=1: several ranks share the GPUs that are present (a one-GPU box), process group over gloo.
     # Only for exercising the multi-rank code path; RCCL refuses two ranks on one device, so the exchange falls back
     # to torch.distributed P2P (through host memory) and the numbers mean nothing.
-    rehearsal = os.environ.get("GH_BENCH_REHEARSAL") == "1"
+    # GH_BENCH_REHEARSAL=loopback: as above, and every rank drives the NATIVE step code path with a private one-rank
+    # communicator in loopback mode (its neighbours are itself), results unchecked.
+    rehearsal = os.environ.get("GH_BENCH_REHEARSAL") in ("1", "loopback")
+    rehearsal_loopback = os.environ.get("GH_BENCH_REHEARSAL") == "loopback"
     if rehearsal:
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -195,60 +198,91 @@ def main() -> int:
         exchange = "torch.distributed P2P (batch_isend_irecv over RCCL)"
         if args.exchange == "native":
             try:
-                native = sharding.NativeHaloComm(rank, world)
+                if rehearsal_loopback:
+                    native = sharding.NativeHaloComm(0, 1)
+                    native.set_loopback(True)
+                else:
+                    native = sharding.NativeHaloComm(rank, world)
             except Exception as exc:
                 exchange_note = f"native communicator unavailable on rank {rank}: {exc}"
             if not all_ranks_agree(native is not None):
                 native = None
 
-    def make_runner(native_comm):
-        if fused:
-            return sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap, native_comm=native_comm)
-        return sharding.ShardedGraySobel(geom, backend, device, overlap=overlap, native_comm=native_comm)
-
-    # synthetic frame shard, resident in HBM before the timed region
+    # Synthetic frames, resident in HBM before the timed region.  N = 1: one frame.  N > 1: a ring of three frames (a
+    # stream of frames, step k works on frame k % 3), so that the halo rows of a later frame can be exchanged while the
+    # current one is processed -- every step still does one full exchange and one full pass over a 16384-wide shard.
+    NBUF = 1 if world == 1 else 3
     gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    frame = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
-    runner = make_runner(native)
-    if fused:
-        runner.shard.copy_(frame)
-        rgb = runner.shard
-        del frame
-    else:
-        rgb = frame
-    run_once = (lambda r: r.step()) if fused else (lambda r: r.step(rgb))
-    if native is not None:
-        # first frame through both exchange paths: the C++ path must reproduce the torch.distributed one bit for bit
-        ref_runner = make_runner(None)
+    runners, rgbs = [], []
+    for i in range(NBUF):
+        gen.manual_seed(1234 + rank + 1000 * i)
+        frame = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
         if fused:
-            ref_runner.shard.copy_(rgb)
-        try:
-            run_once(ref_runner)
-            run_once(runner)
-            torch.cuda.synchronize()
-            same = bool(torch.equal(ref_runner.edge, runner.edge))
-        except Exception as exc:
-            same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
-        if all_ranks_agree(same):
-            exchange = "libgrayhip RCCL communicator (ncclSend/ncclRecv group + shard launches issued from C++, csrc/comm.hip)"
-            del ref_runner
+            r = sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap)
+            r.shard.copy_(frame)
+            rgbs.append(r.shard)
+            del frame
         else:
-            exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frame; using torch"
-            runner, native = ref_runner, None
-            rgb = runner.shard if fused else rgb
-        torch.cuda.empty_cache()
-    edge = runner.edge
-
+            r = sharding.ShardedGraySobel(geom, backend, device, overlap=overlap)
+            rgbs.append(frame)
+        runners.append(r)
+    runner, rgb = runners[0], rgbs[0]
+    halo_bufs = [r.rgb for r in runners] if fused else [r.luma for r in runners]     # (rows+2)-row buffers, halo rows 0 / rows+1
     stream = torch.cuda.current_stream()
     single = world == 1
+
+    def torch_step(k):            # exchange issued by torch.distributed P2P ops, frame k % NBUF, result in that runner's edge
+        r = runners[k % NBUF]
+        return r.step() if fused else r.step(rgbs[k % NBUF])
+
+    step_impl, edge_of = torch_step, (lambda k: runners[k % NBUF].edge)
+    if native is not None:
+        # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
+        AHEAD = 2
+        edge_native = torch.empty((rows, W), dtype=torch.uint8, device=device)
+        try:
+            if fused:
+                pstep = native.bind_fused_step_pipelined(halo_bufs, edge_native, rows, mode, ahead=AHEAD)
+                native_step = pstep
+            else:
+                pstep = native.bind_sobel_step_pipelined(halo_bufs, edge_native, rows, ahead=AHEAD)
+                grays = [backend.bind_gray_to_plane(rgbs[i], halo_bufs[i][1:rows + 1]) for i in range(NBUF)]
+                for g_ in grays:
+                    g_()          # prologue: luma of every frame of the ring exists before its halo is first requested
+
+                def native_step(k):
+                    grays[(k + AHEAD) % NBUF]()      # luma of the frame whose halo is requested in this step
+                    pstep(k)
+            # every frame of the ring through both paths: the C++ path must reproduce torch.distributed bit for bit
+            same = True
+            for k in range(NBUF):
+                torch_step(k)
+            torch.cuda.synchronize()
+            for k in range(2 * NBUF):
+                native_step(k)
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(edge_native, runners[k % NBUF].edge))
+        except Exception as exc:
+            same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
+        if all_ranks_agree(same or rehearsal_loopback):
+            exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
+                        f"the halo rows of frame k+{AHEAD} travel while frame k is processed")
+            step_impl, edge_of = native_step, (lambda k: edge_native)
+        else:
+            exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
+            native = None
+
     n_ev = 3 if (single and not fused) else 2
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
+    edge = runner.edge
+    step_no = [0]
 
     def step(ev=None):
+        k = step_no[0]
+        step_no[0] += 1
         if ev:
             ev[0].record(stream)
-        if fused:
+        if single and fused:
             runner.step()
         elif single:
             api.gray_to_plane(rgb, mode, out=runner.luma[1:rows + 1])
@@ -256,7 +290,7 @@ def main() -> int:
                 ev[1].record(stream)
             api.sobel_rows(runner.luma, edge, rows, True, True)
         else:
-            runner.step(rgb)
+            step_impl(k)
         if ev:
             ev[-1].record(stream)
 
@@ -292,26 +326,27 @@ def main() -> int:
 
     # N > 1: every rank's halo rows must hold its neighbours' edge rows (what the last step's exchange delivered)
     halo_ok = True
+    last = step_no[0] - 1                       # the frame of the last step is the one checked
+    rgb, edge, hbuf = rgbs[last % NBUF], (edge_of(last) if not single else edge), halo_bufs[last % NBUF]
     if world > 1:
         firsts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
         lasts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
         dist.all_gather(firsts, rgb[0].contiguous())
         dist.all_gather(lasts, rgb[rows - 1].contiguous())
+        up_row, down_row = hbuf[0], hbuf[rows + 1]
         if fused:
-            up_row, down_row = runner.rgb[0], runner.rgb[rows + 1]
             conv = lambda t: t
         else:
-            up_row, down_row = runner.luma[0], runner.luma[rows + 1]
             conv = lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W)
         if rank > 0:
             halo_ok &= bool(torch.equal(up_row, conv(lasts[rank - 1])))
         if rank < world - 1:
             halo_ok &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
-        halo_ok = all_ranks_agree(halo_ok)
+        halo_ok = all_ranks_agree(halo_ok or rehearsal_loopback)
 
     # parity spot check of what was just timed (checker only; not in the timed region)
     check = "skipped"
-    if not args.no_check and rank == 0:
+    if not args.no_check and rank == 0 and not rehearsal_loopback:
         try:
             import numpy as np
             from oracle import pyoracle as O
@@ -322,7 +357,7 @@ def main() -> int:
             good = np.array_equal(got[1:], want[1:]) and not got[0].any()
             if world > 1 and fused and rows > 40:
                 # the shard's last rows, which depend on the halo row received from rank 1
-                src = runner.rgb[rows - 30:rows + 2].cpu().numpy()          # buffer rows = shard rows rows-31 .. rows-1 + the halo row
+                src = hbuf[rows - 30:rows + 2].cpu().numpy()                # buffer rows = shard rows rows-31 .. rows-1 + the halo row
                 want = O.sobel(O.gray_to_plane(src, mode))[1:-1]             # shard rows rows-30 .. rows-1
                 good = good and np.array_equal(edge[rows - 30:rows].cpu().numpy(), want)
             check = "ok" if good else "MISMATCH"
@@ -404,7 +439,8 @@ def main() -> int:
                 "width": W, "height": H_total, "rows_per_gpu": rows,
                 "parallelism": "single GPU" if world == 1 else
                                f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv"
-                               + ("" if args.no_overlap else ", overlapped with the interior rows"),
+                               + (", beside the kernels of an earlier frame of the ring (software-pipelined)" if native is not None else
+                                  ("" if args.no_overlap else ", overlapped with the interior rows")),
                 "halo_exchange": exchange + (f" [{exchange_note}]" if exchange_note else ""),
             },
             "roofline": roofline,

@@ -164,6 +164,17 @@ GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream);
+/* Pipelined form for a STREAM of frames kept in a few such buffers: `cur` -- whose halo rows were requested by an
+ * earlier call, where it was `prefetch` -- is processed by ONE launch over the whole shard while the halo rows of
+ * `prefetch` (a frame that will be `cur` in a later call; its rows 1 / rows must already be in place, enqueued on
+ * `stream`) are exchanged on the side stream.  The exchange latency, the cross-queue event latency and the two one-row
+ * launches of the form above leave the critical path (request the halo two frames ahead: three buffers).  If cur's
+ * halo was never requested (first calls, buffer changed) it is exchanged first; prefetch may be NULL or equal to cur.
+ * At most 4 requests are remembered. */
+GH_API int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *prefetch_rgb_buf, uint8_t *edge,
+                                               int width, int rows, int channels, int mode, gh_stream_t stream);
+GH_API int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge,
+                                               int width, int rows, gh_stream_t stream);
 
 /* The reference's own symbols (same prototypes as monolithic/include/ headers).  They return void in
  * the reference, so a failure is reported on stderr and the process is aborted -- never a

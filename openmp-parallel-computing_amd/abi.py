@@ -60,6 +60,8 @@ SIGNATURES = {
     "gh_comm_allreduce_sum_u64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
     "gh_sharded_fused_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
+    "gh_sharded_fused_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_sharded_sobel_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "convert_to_grayscale": (None, [_u8p, C.c_int, C.c_int, C.c_int]),
     "sobel_edge": (None, [_u8p, _u8p, C.c_int, C.c_int]),
     "gh_selftest_sobel_mag": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -88,6 +88,12 @@ struct Comm {
     hipStream_t side = nullptr;          // the exchange runs here, beside the interior rows on the caller's stream
     hipEvent_t ready = nullptr, landed = nullptr;
     bool loopback = false;               // rehearsal on one GPU: both neighbours are this rank (ncclSend/ncclRecv to self)
+    // pipelined steps: buffers whose halo rows the side stream has already been asked to fill, and the event that says
+    // they have landed.  A few entries, so that a halo can be requested two or three frames ahead.
+    static constexpr int kPrefetch = 4;
+    const void *pf_buf[kPrefetch] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pf_landed[kPrefetch] = {nullptr, nullptr, nullptr, nullptr};
+    int pf_next = 0;
 };
 
 }  // namespace
@@ -121,9 +127,14 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         delete c;
         return gh_set_error(GH_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
     }
-    GH_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    // high priority: its own hardware queue (a plain second stream may be mapped onto the caller's queue, which would
+    // serialise the exchange with the shard kernels), and the small exchange kernel is not stuck behind a full grid
+    int prio_least = 0, prio_greatest = 0;
+    GH_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    GH_HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest));
     GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
+    for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
     *out = c;
     return GH_OK;
 }
@@ -146,6 +157,8 @@ int gh_comm_destroy(gh_comm_t comm)
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->landed) (void)hipEventDestroy(c->landed);
+    for (int i = 0; i < Comm::kPrefetch; ++i)
+        if (c->pf_landed[i]) (void)hipEventDestroy(c->pf_landed[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return GH_OK;
@@ -213,7 +226,81 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     return launch(0, rows, up < 0, down < 0);
 }
 
+// Pipelined form for a stream of frames held in a few buffers: the halo rows of `prefetch` (a frame that will be `cur`
+// in a later call) are exchanged on the side stream WHILE `cur` -- whose halo rows were requested by an earlier call --
+// is processed by one launch over the whole shard.  Per step the caller's stream sees a single kernel; the exchange
+// latency, the cross-queue event latency (~20 us on this runtime when the wait is reached before the signal) and the
+// two one-row launches of the form above leave the critical path once the halo is requested two frames ahead.  If
+// cur's halo has not been requested (first calls, or the caller changed buffers), it is exchanged first.
+template <typename Launch>
+static int sharded_step_pipelined(Comm *c, uint8_t *cur, uint8_t *prefetch, size_t row_bytes, int rows, hipStream_t s, Launch launch)
+{
+    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback) up = down = c->rank;
+    if (up < 0 && down < 0) return launch(cur, 1, 1);
+    auto find = [&](const void *p) {
+        for (int i = 0; i < Comm::kPrefetch; ++i)
+            if (c->pf_buf[i] == p) return i;
+        return -1;
+    };
+    auto exchange = [&](uint8_t *buf) -> int {      // returns the table slot (>= 0) or a negative status
+        // reads buf's rows 1 / rows (written by earlier work on s), overwrites its halo rows (last read by earlier work on s)
+        const int slot = c->pf_next;
+        c->pf_next = (c->pf_next + 1) % Comm::kPrefetch;
+        c->pf_buf[slot] = nullptr;
+        if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
+            return -gh_set_error(GH_ERR_HIP, "event hand-over to the exchange stream failed");
+        if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
+                                          row_bytes, c->side))
+            return rc < 0 ? rc : -rc;
+        if (hipEventRecord(c->pf_landed[slot], c->side) != hipSuccess) return -gh_set_error(GH_ERR_HIP, "hipEventRecord failed");
+        c->pf_buf[slot] = buf;
+        return slot;
+    };
+    int slot = find(cur);
+    if (slot < 0) {
+        slot = exchange(cur);
+        if (slot < 0) return -slot;
+    }
+    GH_HIP_TRY(hipStreamWaitEvent(s, c->pf_landed[slot], 0));   // cur's halo rows have landed
+    c->pf_buf[slot] = nullptr;
+    if (prefetch && prefetch != cur && find(prefetch) < 0) {
+        // `ready` is recorded BEFORE cur's kernel is launched, so the exchange runs beside it
+        const int ps = exchange(prefetch);
+        if (ps < 0) return -ps;
+    }
+    return launch(cur, up < 0, down < 0);
+}
+
 extern "C" {
+
+int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *prefetch_rgb_buf, uint8_t *edge, int width, int rows,
+                                        int channels, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(cur_rgb_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width * channels;
+    return sharded_step_pipelined(c, cur_rgb_buf, prefetch_rgb_buf, rb, rows, (hipStream_t)stream, [&](uint8_t *buf, int tb, int bb) {
+        return gh_gray_sobel_fused_rows_dev(buf + rb, edge, width, rows, channels, mode, tb, bb, stream);
+    });
+}
+
+int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge, int width, int rows,
+                                        gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(cur_luma_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width;
+    return sharded_step_pipelined(c, cur_luma_buf, prefetch_luma_buf, rb, rows, (hipStream_t)stream, [&](uint8_t *buf, int tb, int bb) {
+        return gh_sobel_u8_rows_dev(buf + rb, edge, width, rows, tb, bb, stream);
+    });
+}
 
 int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels, int mode, gh_stream_t stream)
 {

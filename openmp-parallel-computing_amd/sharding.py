@@ -139,6 +139,33 @@ class NativeHaloComm:
         fn, chk, h, src, dst = self.lib.gh_sharded_fused_step_dev, self.abi.check, self.handle, rgb_buf.data_ptr(), edge.data_ptr()
         return lambda: chk(fn(h, src, dst, w, rows, c, mode, torch.cuda.current_stream().cuda_stream), "gh_sharded_fused_step_dev")
 
+    def bind_fused_step_pipelined(self, bufs, edge, rows, mode, ahead=None):
+        """bufs: the (rows+2, w, c) frame buffers the stream of frames cycles through.  The returned closure takes the
+        step number k: it processes bufs[k % n] while the halo rows of bufs[(k+ahead) % n] are exchanged beside it
+        (ahead = n - 1: as far ahead as the ring allows; 2 hides the exchange and the cross-queue event latency)."""
+        import torch
+        w, c = bufs[0].shape[1], bufs[0].shape[2]
+        for b in bufs:
+            assert tuple(b.shape) == (rows + 2, w, c) and b.is_contiguous()
+        assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
+        fn, chk, h, dst = self.lib.gh_sharded_fused_step_pipelined_dev, self.abi.check, self.handle, edge.data_ptr()
+        ptrs, n = [b.data_ptr() for b in bufs], len(bufs)
+        a = max(n - 1, 0) if ahead is None else ahead
+        return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + a) % n], dst, w, rows, c, mode, torch.cuda.current_stream().cuda_stream),
+                             "gh_sharded_fused_step_pipelined_dev")
+
+    def bind_sobel_step_pipelined(self, lumas, edge, rows, ahead=None):
+        import torch
+        w = lumas[0].shape[1]
+        for b in lumas:
+            assert tuple(b.shape) == (rows + 2, w) and b.is_contiguous()
+        assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
+        fn, chk, h, dst = self.lib.gh_sharded_sobel_step_pipelined_dev, self.abi.check, self.handle, edge.data_ptr()
+        ptrs, n = [b.data_ptr() for b in lumas], len(lumas)
+        a = max(n - 1, 0) if ahead is None else ahead
+        return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + a) % n], dst, w, rows, torch.cuda.current_stream().cuda_stream),
+                             "gh_sharded_sobel_step_pipelined_dev")
+
     def bind_sobel_step(self, luma_buf, edge, rows):
         import torch
         w = luma_buf.shape[1]

@@ -467,3 +467,61 @@ def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h
         del geom
     finally:
         native_comm.set_loopback(False)
+
+
+def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
+    """Pipelined sharded step: frame k is processed while frame k+1's halo rows are exchanged; two different frames
+    alternate, so a halo row that reached the wrong buffer (or arrived late) changes the result."""
+    t = torch_mod
+    w, h = 2064, 37
+    frames = [oracle.frame_rand(w, h, 3, seed=s) for s in (11, 12, 13)]
+    wants = []
+    for img in frames:
+        padded = np.concatenate([img[:1], img, img[-1:]], axis=0)
+        e = oracle.sobel(oracle.gray_to_plane(padded, 0))[1:-1]
+        e[:, 0] = 0
+        e[:, -1] = 0
+        wants.append(e)
+    native_comm.set_loopback(True)
+    try:
+        bufs = []
+        for img in frames:
+            b = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+            b[1:h + 1] = dev(t, img)
+            bufs.append(b)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_step_pipelined(bufs, edge, h, 0)
+        for k in range(6):
+            step(k)
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), wants[k % 3]), k
+        # no synchronisation between steps: results of the last step only
+        for k in range(6, 17):
+            step(k)
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), wants[16 % 3])
+        # halo requested one frame ahead on a ring of two
+        step_b = native_comm.bind_fused_step_pipelined(bufs[:2], edge, h, 0)
+        for k in range(5):
+            step_b(k)
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), wants[4 % 2])
+        # split pipeline: luma halo rows
+        backend = pkg.sharding.HipBackend(0)
+        lumas = []
+        for img in frames:
+            l = t.zeros((h + 2, w), dtype=t.uint8, device="cuda")
+            backend.gray_to_plane(dev(t, img), l[1:h + 1])
+            lumas.append(l)
+        step2 = native_comm.bind_sobel_step_pipelined(lumas, edge, h)
+        for k in range(5):
+            step2(k)
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), wants[4 % 3])
+        # a single buffer (no prefetch possible) still works
+        step1 = native_comm.bind_fused_step_pipelined(bufs[:1], edge, h, 0)
+        step1(0); step1(1)
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), wants[0])
+    finally:
+        native_comm.set_loopback(False)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Host and GPU cost of one natively issued sharded step (csrc/comm.hip) for the shard sizes of a 16384^2 frame split
+over 1..8 GPUs, rehearsed on one GPU with the loopback communicator (ncclSend/ncclRecv to self).  Developer tool."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("openmp-parallel-computing_amd"); api = pkg.hostapi; api.init(0)
+comm = pkg.sharding.NativeHaloComm(0, 1); comm.set_loopback(True)
+W = 16384
+WORLDS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+NSTEP = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+for world in WORLDS:
+    rows = 16384 // world
+    buf = torch.randint(0, 256, (rows + 2, W, 3), dtype=torch.uint8, device="cuda")
+    edge = torch.empty((rows, W), dtype=torch.uint8, device="cuda")
+    step = comm.bind_fused_step(buf, edge, rows, 0)
+    whole = lambda: api.gray_sobel_fused_rows(buf, edge, rows, 0, True, True)
+    buf2, buf3 = buf.clone(), buf.clone()
+    pstep = comm.bind_fused_step_pipelined([buf, buf2], edge, rows, 0)
+    pstep3 = comm.bind_fused_step_pipelined([buf, buf2, buf3], edge, rows, 0)
+    cnt = [0]
+    def piped():
+        pstep(cnt[0]); cnt[0] += 1
+    def piped3():
+        pstep3(cnt[0]); cnt[0] += 1
+    for name, fn in (("native sharded step (exchange || interior, then edge rows)", step), ("native pipelined step, halo 1 frame ahead", piped),
+                     ("native pipelined step, halo 2 frames ahead", piped3), ("single launch, no exchange", whole)):
+        if ONLY and ONLY not in name: continue
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        n = NSTEP
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); a.record()
+        for _ in range(n): fn()
+        t1 = time.perf_counter(); b.record(); b.synchronize(); t2 = time.perf_counter()
+        print(f"shard of 1/{world} ({rows} rows): {name:62s} host enqueue {1e6*(t1-t0)/n:7.1f} us/step  wall {1e6*(t2-t0)/n:7.1f} us/step  "
+              f"gpu {1e3*a.elapsed_time(b)/n:7.1f} us/step  -> {W*rows/( (t2-t0)/n)/1e6:9.0f} Mpx/s per rank")
+comm.close()
