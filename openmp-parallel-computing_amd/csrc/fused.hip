@@ -6,10 +6,12 @@
 // luma (rows above/below a band, pixels left/right of a strip) is recomputed from RGB, which is also the
 // zero-communication alternative to exchanging luma halo rows between shards.
 //
-//   k_fused_stream      default: strip streaming (stream_core.h).  Per row a wave loads its 3 KiB (RGB) of the row
-//                       with fully coalesced dwordx4 loads, de-interleaves them through a private LDS slab so
-//                       that every lane owns 16 consecutive pixels, converts to luma in f32 and feeds the f32
-//                       Sobel row step directly (no byte round trip).
+//   k_fused_dma         default for RGB8, width >= 1024: strip streaming (stream_core.h) with an LDS row ring filled by
+//                       LDS-DMA (global_load_lds_dwordx4, three rows deep): a wave's 3 KiB of a row lands lane-linear
+//                       in LDS, every lane reads back its 16 consecutive pixels (48 B), converts to luma in f32 and
+//                       feeds the f32 Sobel row step directly (no byte round trip).  GH_FUSED_DMA=0 turns it off.
+//   k_fused_stream      RGBA8 / narrow frames: the same strip streaming, rows staged through registers
+//                       (coalesced dwordx4 loads -> ds_write -> ds_read de-interleave).
 //   k_gray_sobel_fused  the LDS-tile form (sobel_tile.h); GH_FUSED_IMPL=tile
 #include "sobel_tile.h"
 #include "stream_core.h"
@@ -22,6 +24,8 @@ namespace {
 
 using namespace sobel_tile;
 using stream_core::row_readable;
+using stream_core::BandPlan;
+using stream_core::make_band_plan;
 
 // luma of two pixels as integer-valued floats (packed f32: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32):
 // trunc(y) == (float)(unsigned char)y for 0 <= y <= 255; same arithmetic as gh_luma, minus the float->int->float
@@ -230,64 +234,6 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 // the only loads younger than row i's are those of rows i+1 .. i+D-1 (4 instructions each); output stores in between
 // only make the count conservative.  The last strip of a row is shifted left to end at the frame edge (all strips are
 // full; the overlap is recomputed and stored twice with identical bytes), so no lane of a DMA piece is ever masked.
-__device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_slot)
-                 : "memory");
-}
-__device__ __forceinline__ void glds_dword(uint32_t lds_dst, const uint8_t *rowb, uint32_t voff)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_dst)
-                 : "memory");
-}
-// Band plan of a strip kernel launch: level l has n[l] bands of R[l] rows starting at row y[l]; the last level runs to the
-// end of the frame.  Workgroups are dispatched in blockIdx order, so the short bands of the last levels are the ones still
-// running when the grid drains.
-struct BandPlan {
-    int n[2];
-    int R[3];
-    int y[3];
-    int bands;      // total
-};
-inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
-{
-    BandPlan p{};
-    const int full0 = (rows + R0 - 1) / R0;
-    if (n0 < 0 || n0 >= full0 || R1 <= 0) {        // single level
-        p.n[0] = full0; p.n[1] = 0; p.R[0] = p.R[1] = p.R[2] = R0; p.y[0] = 0; p.y[1] = p.y[2] = full0 * R0; p.bands = full0;
-        return p;
-    }
-    p.R[0] = R0; p.n[0] = n0; p.y[0] = 0; p.y[1] = n0 * R0; p.R[1] = R1;
-    const int left1 = rows - p.y[1], full1 = (left1 + R1 - 1) / R1;
-    if (n1 < 0 || n1 >= full1 || R2 <= 0) { p.n[1] = full1; p.R[2] = R1; p.y[2] = p.y[1] + full1 * R1; p.bands = n0 + full1; return p; }
-    p.n[1] = n1; p.y[2] = p.y[1] + n1 * R1; p.R[2] = R2;
-    const int left2 = rows - p.y[2];
-    p.bands = n0 + n1 + (left2 + R2 - 1) / R2;
-    return p;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int MODE, int D, int SP>
 __global__ __launch_bounds__(stream_core::BLOCK)
 void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
@@ -327,10 +273,8 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
 
     auto issue_row = [&](int i, int slot) {
         const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
-        const uint64_t ra = (uint64_t)(uintptr_t)(rgb + (ptrdiff_t)yy * w * 3);
-        const uint8_t *rowb = reinterpret_cast<const uint8_t *>(
-            (uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ra)));
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)slot * SLOT));
+        const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * 3);
+        const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         glds_row3k(dst, rowb, voff);
         if (lane < 2) glds_dword(dst + STRIP_PX * 3, rowb, hoff);
     };
@@ -368,7 +312,10 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
                     if (x == 0) out.x &= 0xffffff00u;
                     if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                     if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                    store_strip_p<SP % 10>(edge + (size_t)y * w + xw, lane, out);
+                    if (SP >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
+                        store_strip_p<SP % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
+                    else
+                        store_strip_p<SP % 10>(edge + (size_t)y * w + xw, lane, out);
                 }
             }
         }
@@ -457,7 +404,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             } while (0)
             if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }
             else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else GH_FD(2, 2); }
-            else { if (sp == 0) GH_FD(3, 0); else if (sp == 1) GH_FD(3, 1); else if (sp == 10) GH_FD(3, 10); else if (sp == 12) GH_FD(3, 12); else GH_FD(3, 2); }
+            else { if (sp == 0) GH_FD(3, 0); else if (sp == 1) GH_FD(3, 1); else if (sp == 10) GH_FD(3, 10); else if (sp == 12) GH_FD(3, 12); else if (sp == 22) GH_FD(3, 22); else GH_FD(3, 2); }
 #undef GH_FD
             GH_LAUNCH_CHECK();
             return GH_OK;

@@ -2,8 +2,10 @@
 //
 // Replaces monolithic/src/sobel.c:6-25 (sobel_edge).  Bound: HBM, 1 R + 1 W byte per pixel, no MFMA.
 //
-//   k_sobel_stream : default fast path (width % 16 == 0, 16-byte aligned planes): strip streaming, 3x3 reuse in
-//                    registers, halo through DPP (stream_core.h)
+//   k_sobel_dma    : default fast path (width % 16 == 0, width >= 1024, 16-byte aligned planes): strip streaming -- 3x3
+//                    reuse in registers, halo through DPP (stream_core.h) -- with rows brought HBM -> LDS by LDS-DMA
+//                    (global_load_lds_dwordx4), three rows deep; GH_SOBEL_DMA=0 turns it off
+//   k_sobel_stream : the same strip streaming with register-staged loads (narrow frames, GH_SOBEL_DMA=0)
 //   k_sobel_tiled  : the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h); GH_SOBEL_IMPL=tile
 //   k_sobel_px     : one pixel per lane, any geometry / alignment (odd widths, unaligned planes)
 #include "sobel_tile.h"
@@ -99,6 +101,99 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
         compute_chunk(ch, qa, ha);
         load_chunk(ch + 2, qa, ha);
         if (ch + 1 < NCH) compute_chunk(ch + 1, qb, hb2);
+    }
+}
+
+// ---- LDS-DMA form (width >= 1024): a wave's 1 KiB of each row goes HBM -> LDS directly, D rows deep -------------------
+// Same ring as fused.hip's k_fused_dma (one global_load_lds_dwordx4 + one halo dword per row, own vmcnt accounting),
+// but the prefetch depth costs LDS (1 KiB per row and wave) instead of registers, so it can be deep: the plane kernel
+// moves only 2 B/px, a wave's row is consumed in ~550 cycles and the register-staged form cannot keep enough bytes
+// in flight at 3 waves per SIMD.  The last strip of a row is shifted left to end at the frame edge (all strips full).
+template <int D, int PROBE = 0>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
+                                                                 int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
+{
+    using namespace stream_core;
+    constexpr int SLOT = STRIP_PX + 16;                          // one strip row + the halo dword pair
+    constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
+    static_assert(3 * (D - 1) <= 60, "vmcnt is 6 bits");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
+    if (xw >= w) return;
+    if (xw + STRIP_PX > w) xw = w - STRIP_PX;
+    const int x = xw + 16 * lane;
+    int R = plan.R[0], y0 = gy_i * plan.R[0];
+    if (gy_i >= plan.n[0]) {
+        const int g1 = gy_i - plan.n[0];
+        R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
+        if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
+    }
+    const int nrows = min(R, rows - y0) + 2;
+    const int nch = (nrows + CHK - 1) / CHK;
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    const f32x2 half2 = half2_reg();
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its byte 3),
+    //              lane 1 -> the 4 bytes after the strip's last byte (pixel xw+1024 = its byte 0); clamped when outside
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + STRIP_PX);
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + STRIP_PX >= w)) hoff = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+
+    StateF2 st;
+    st.clear();
+
+    auto issue_row = [&](int i, int slot) {
+        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        glds_row1k(d, rowb, voff);
+        if (lane < 2) glds_dword(d + STRIP_PX, rowb, hoff);
+    };
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue_row(i, i);
+
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool steady = ch >= 2;      // every one of the last D-1 iterations also issued its output store (see k_fused_dma)
+#pragma unroll
+        for (int j = 0; j < CHK; ++j) {
+            const int i = ch * CHK + j;
+            if (i < nrows) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
+                if (i + D - 1 < nrows) {
+                    issue_row(i + D - 1, (j + D - 1) % D);
+                    if (steady) wait_vm<3 * (D - 1)>(); else wait_vm<2 * (D - 1)>();
+                } else {
+                    wait_vm<0>();
+                }
+                const uint8_t *slotp = &ring[wave][j % D][0];
+                const uint4 q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
+                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
+                uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+                uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+                if (lane == 0) ql = hh.x;
+                if (lane == 63) qr = hh.y;
+                // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
+                const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
+                f32x2 G[10];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+                G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
+                G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
+                uint4 out = (j & 1) ? rowf2<1, 1, PROBE>(st, G, half2) : rowf2<0, 1, PROBE>(st, G, half2);
+                if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
+                    const int y = y0 + i - 2;
+                    if (x == 0) out.x &= 0xffffff00u;
+                    if (x + 15 == w - 1) out.w &= 0x00ffffffu;
+                    if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+                    store_strip(dst + (size_t)y * w + xw, lane, out);
+                }
+            }
+        }
     }
 }
 
@@ -216,6 +311,18 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
+        const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
+        if (dma && core == 1 && width >= stream_core::STRIP_PX) {
+            const stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+            if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt
+            else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 6) k_sobel_dma<6><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else k_sobel_dma<8><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            GH_LAUNCH_CHECK();
+            return GH_OK;
+        }
 #define GH_SOBEL_LAUNCH(R_, C_)                                                                                      \
         do {                                                                                                         \
             if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);       \

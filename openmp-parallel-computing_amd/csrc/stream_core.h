@@ -164,7 +164,7 @@ struct StateF2 {
 
 // RTZ = 1: the kernel runs with MODE.fp_round = toward zero (allowed only when it contains no rounding-sensitive
 // float op), so v_cvt_pk_u8_f32 floors by itself and the "- 0.5" is not needed.
-template <int PAR, int RTZ = 0>
+template <int PAR, int RTZ = 0, int PROBE_NOSQRT = 0>
 __device__ __forceinline__ uint4 rowf2(StateF2 &st, const f32x2 (&G)[10], f32x2 half2)
 {
     f32x2 s[9];
@@ -181,8 +181,12 @@ __device__ __forceinline__ uint4 rowf2(StateF2 &st, const f32x2 (&G)[10], f32x2 
         st.h1p[k] = h1; st.cp[k] = c; st.h2r[PAR][k] = h2;
         const f32x2 m = __builtin_elementwise_fma(gx, gx, __builtin_elementwise_fma(gy, gy, half2));   // exact: < 2^22
         f32x2 f;
-        f.x = __builtin_amdgcn_sqrtf(m.x);
-        f.y = __builtin_amdgcn_sqrtf(m.y);
+        if (PROBE_NOSQRT) {              // timing probe only (wrong results): what do the 16 v_sqrt_f32 per row cost?
+            f = m * half2;
+        } else {
+            f.x = __builtin_amdgcn_sqrtf(m.x);
+            f.y = __builtin_amdgcn_sqrtf(m.y);
+        }
         if (!RTZ) f = f - half2;                                            // see mag_pack_rne / mag_pack_rtz
         r[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(f.x, k & 3, r[k >> 2]);              // pixel k
         r[2 + (k >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(f.y, k & 3, r[2 + (k >> 2)]);  // pixel k + 8
@@ -294,5 +298,87 @@ __device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int
 {
     return (yy >= 0 && yy < rows) || (yy == -1 && !zero_top) || (yy == rows && !zero_bot);
 }
+
+// ---- LDS-DMA (global_load_lds_*) helpers of the ring kernels (fused.hip k_fused_dma, sobel.hip k_sobel_dma) -------------
+// hipcc does not count asm memory operations: the kernels place their own s_waitcnt vmcnt(N) (wait_vm).  M0 carries the
+// wave-uniform LDS destination; each lane's data lands at M0 + instruction offset + lane * size.
+__device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_slot)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_row1k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_slot)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_dword(uint32_t lds_dst, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_dst)
+                 : "memory");
+}
+// Band plan of a strip kernel launch: level l has n[l] bands of R[l] rows starting at row y[l]; the last level runs to the
+// end of the frame.  Workgroups are dispatched in blockIdx order, so the short bands of the last levels are the ones still
+// running when the grid drains.
+struct BandPlan {
+    int n[2];
+    int R[3];
+    int y[3];
+    int bands;      // total
+};
+inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
+{
+    BandPlan p{};
+    const int full0 = (rows + R0 - 1) / R0;
+    if (n0 < 0 || n0 >= full0 || R1 <= 0) {        // single level
+        p.n[0] = full0; p.n[1] = 0; p.R[0] = p.R[1] = p.R[2] = R0; p.y[0] = 0; p.y[1] = p.y[2] = full0 * R0; p.bands = full0;
+        return p;
+    }
+    p.R[0] = R0; p.n[0] = n0; p.y[0] = 0; p.y[1] = n0 * R0; p.R[1] = R1;
+    const int left1 = rows - p.y[1], full1 = (left1 + R1 - 1) / R1;
+    if (n1 < 0 || n1 >= full1 || R2 <= 0) { p.n[1] = full1; p.R[2] = R1; p.y[2] = p.y[1] + full1 * R1; p.bands = n0 + full1; return p; }
+    p.n[1] = n1; p.y[2] = p.y[1] + n1 * R1; p.R[2] = R2;
+    const int left2 = rows - p.y[2];
+    p.bands = n0 + n1 + (left2 + R2 - 1) / R2;
+    return p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wave-uniform 64-bit pointer / 32-bit value into SGPRs (inline asm "s" operands inside divergent code need it spelled out)
+__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return reinterpret_cast<const uint8_t *>(
+        (uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a)));
+}
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 }  // namespace stream_core

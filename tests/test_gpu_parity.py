@@ -223,6 +223,26 @@ def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
             assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), (knobs, w, h, mode)
 
 
+@pytest.mark.parametrize("knobs", [{"GH_SOBEL_DMA": "0"}, {"GH_SOBEL_DMA": "2"}, {"GH_SOBEL_DMA": "3"}, {"GH_SOBEL_DMA": "4"}, {"GH_SOBEL_DMA": "6"},
+                                   {"GH_SOBEL_DMA": "8"}, {"GH_SOBEL_DMA": "6", "GH_SOBEL_R": "16"}, {"GH_SOBEL_DMA": "0", "GH_SOBEL_R": "32"}])
+def test_sobel_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
+    """Register-staged and LDS-DMA forms of the plane Sobel kernel, every ring depth: bit-exact, including bands
+    (halo rows above / below) and the shifted last strip of widths that are not a multiple of 1024."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for (w, h) in ((2064, 150), (1024, 67), (4096, 3), (1040, 1), (3088, 2)):
+        plane = oracle.frame_rand(w, h, 1, seed=w + 3 * h).reshape(h, w)
+        want = oracle.sobel(plane)
+        assert np.array_equal(pkg.hostapi.sobel(dev(torch_mod, plane)).cpu().numpy(), want), (knobs, w, h)
+    # a middle band: rows above and below are real halo rows
+    w, h = 2064, 40
+    plane = oracle.frame_rand(w, h + 2, 1, seed=5).reshape(h + 2, w)
+    want = oracle.sobel(plane)[1:-1]
+    got = torch_mod.empty((h, w), dtype=torch_mod.uint8, device="cuda")
+    pkg.hostapi.sobel_rows(dev(torch_mod, plane), got, h, False, False)
+    assert np.array_equal(got.cpu().numpy(), want), knobs
+
+
 # ---- the reference's drivers and historic kernels -----------------------------------------------
 
 def test_pipeline_matches_reference_cli_fixtures(pkg, jpg_crop, cli_crop, torch_mod):
