@@ -382,25 +382,37 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
                 else k_fused_stream<GH_MODE_IEEE, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);                     \
             }                                                                                                             \
         } while (0)
-        // strip height: taller strips re-read fewer halo rows (2 per strip) but a shard must still fill the 256 CUs
-        const int dma = GH_TUNE_INT("GH_FUSED_DMA", 3);    // ring depth D (0 = off)
-        if (dma && channels == 3 && width >= stream_core::STRIP_PX) {
+        // LDS-DMA ring kernel.  Tuning found on MI355X (tools/ab_fused.py, 16384-wide frames):
+        //  * band height 64 is the sweet spot whenever it still gives every CU a workgroup (69-73 % of 8 TB/s for 4096 ..
+        //    16384-row frames); 32- and 128-row bands are 5-15 % slower at the same frame, 16-row bands pay 12.5 % halo rows;
+        //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
+        //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
+        int dma = GH_TUNE_INT("GH_FUSED_DMA", -1);         // ring depth D (0 = register-staged kernel, -1 = auto)
+        if (dma != 0 && channels == 3 && width >= stream_core::STRIP_PX) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
-            if (rd <= 0) {   // band height: taller bands re-read fewer halo rows, but the launch must still fill the 256 CUs
+            if (rd <= 0) {
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-                rd = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);
+                rd = nb64 >= GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
             }
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // output store policy: 0 default, 1 sc1, 2 nt
-            const int R_ = rd > 0 ? rd : 64;
+            const int R_ = rd;
             // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
             const BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
                                                  GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
             GH_REQUIRE((long long)groups_x * plan.bands < (1ll << 31), "frame too large for one launch");
             const unsigned g = (unsigned)((long long)groups_x * plan.bands);
+            int pad_kb = GH_TUNE_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU
+            if (dma < 0) {
+                const bool big = g > 2u * GH_NUM_CU;
+                dma = big ? 2 : 3;
+                if (pad_kb < 0) pad_kb = big ? 30 : 0;               // 24.7 KiB ring + 30 KiB > 160 KiB / 3: two per CU
+            }
+            if (pad_kb < 0) pad_kb = 0;
+            const size_t pad = (size_t)pad_kb * 1024;
 #define GH_FD(D_, W_)                                                                                                      \
             do {                                                                                                           \
-                if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
-                else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
+                if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
+                else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
             } while (0)
             if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }
             else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else GH_FD(2, 2); }

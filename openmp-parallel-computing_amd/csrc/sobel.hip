@@ -306,7 +306,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         int R = r_env;
         if (R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-            R = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);     // >= 4 workgroups per CU
+            // measured on MI355X (16384-wide planes, tools/ab_fused.py --op sobel): 64-row bands win from 8192 rows up
+            // (66-67 % of 8 TB/s vs 59-61 % for 32 / 16), 32 at 4096 rows, 16 below
+            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
         }
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
@@ -314,7 +316,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
         if (dma && core == 1 && width >= stream_core::STRIP_PX) {
             const stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-            if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt
+            const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
+            if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt
             else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
