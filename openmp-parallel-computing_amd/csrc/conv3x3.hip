@@ -177,12 +177,20 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         const float n = (float)(sgn * norm);
         t.inv = 1.0f / n;
         t.half_inv = 0.5f / n;
-        constexpr int R = 32, C = 2;   // power-of-two band heights measured 10-15 % faster than 30 / 34 / 48 (tools/ubench pitch)
+        // band height: 64 rows whenever that still gives every CU two workgroups (the same rule as the Sobel kernels:
+        // 64-row bands measured 5-10 % faster than 32 on MI355X), else 32, else 16
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);
+        int R = GH_TUNE_INT("GH_CONV_R", 0);
+        if (R != 16 && R != 32 && R != 64) {
+            const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
+            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+        }
         const long long nb = (long long)groups_x * ((height + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        k_conv3x3_stream<R, C><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
+        if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
+        else if (R == 32) k_conv3x3_stream<32, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
+        else k_conv3x3_stream<16, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
     } else {
         Taps t;
         for (int i = 0; i < 9; ++i) t.k[i] = kernel[i];

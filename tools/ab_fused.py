@@ -19,8 +19,10 @@ torch.manual_seed(1)
 rgb = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda")
 plane = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda")
 out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+out3 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") if a.op == "conv" else None
 ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (lambda: api.sobel(plane, out=out), 2),
-       "gray": (lambda: api.gray_to_plane(rgb, 0, out=out), 4)}
+       "gray": (lambda: api.gray_to_plane(rgb, 0, out=out), 4),
+       "conv": (lambda: api.conv3x3(rgb, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16, out=out3), 6)}
 fn, bpp = ops[a.op]
 variants = [("base", {})]
 for v in a.variants:
@@ -38,7 +40,7 @@ for rnd in range(a.rounds + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); [fn() for _ in range(a.reps)]; e1.record(); e1.synchronize()
         if rnd: times[n].append(e0.elapsed_time(e1) / a.reps)
-        else: shas[n] = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]
+        else: shas[n] = hashlib.sha256((out3 if out3 is not None else out).cpu().numpy().tobytes()).hexdigest()[:12]
 print(f"{a.op} {W}x{H}, {a.rounds} interleaved rounds x {a.reps} launches")
 for n, _ in variants:
     t = times[n]; med = statistics.median(t)
