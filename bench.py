@@ -68,11 +68,14 @@ def measured_traffic(kernel_name: str, px: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction), scaled to this launch's
     pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself."""
-    sym = {"gray_sobel_fused_rgb8": "k_fused_dma", "gray_rgb8_to_plane": "k_gray_rgb_to_plane_w", "sobel3x3_u8": "k_sobel_stream"}
+    sym = {"gray_sobel_fused_rgb8": ("k_fused_dma", "k_fused_stream"), "gray_rgb8_to_plane": ("k_gray_rgb_to_plane_w",),
+           "sobel3x3_u8": ("k_sobel_dma", "k_sobel_stream")}
     try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic.json")), key=os.path.getmtime, reverse=True):
-            k = json.load(open(f)).get("kernels", {}).get(sym[kernel_name])
+        latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+        f = os.path.join(ROOT, "profiles", latest, "pmc_hbm_traffic.json")
+        kernels = json.load(open(f)).get("kernels", {})
+        for name in sym[kernel_name]:
+            k = kernels.get(name)
             if k and "hbm_total_bytes" in k:
                 return int(k["hbm_total_bytes"] / (16384 * 16384) * px), os.path.relpath(f, ROOT)
     except Exception:
