@@ -134,6 +134,12 @@ GH_API int gh_sum_rgb8_host(const unsigned char *rgb, size_t npix, uint64_t sums
  * seconds (optional) = wall time of the pipelined loop, registration excluded.  PCIe-bound by construction. */
 GH_API int gh_gray_sobel_streamed_host(const unsigned char *rgb, unsigned char *edge, int width, int height, int channels,
                                        int mode, int tile_rows, int host_buffers_pinned, double *seconds);
+/* The same on a block of `height` rows of a taller host frame -- one rank's share when the frame is split over the GPUs
+ * of a node (BASELINE configs[4] "8 GPUs": bands are independent, zero communication).  Where a side is not the frame
+ * border, the RGB row just outside the block must be readable in host memory at rgb - pitch / rgb + height * pitch. */
+GH_API int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsigned char *edge, int width, int height, int channels,
+                                            int mode, int tile_rows, int host_buffers_pinned, int top_is_border,
+                                            int bottom_is_border, double *seconds);
 
 /* ---- row-sharded frames: one process per GPU, halo rows over RCCL (ncclSend/ncclRecv on xGMI) --------------
  * The reference parallelises rows with OpenMP threads over one shared image (monolithic/src/sobel.c:10,

@@ -45,6 +45,16 @@ struct Ring {
 extern "C" int gh_gray_sobel_streamed_host(const unsigned char *rgb, unsigned char *edge, int width, int height, int channels,
                                            int mode, int tile_rows, int host_buffers_pinned, double *seconds)
 {
+    return gh_gray_sobel_streamed_rows_host(rgb, edge, width, height, channels, mode, tile_rows, host_buffers_pinned, 1, 1, seconds);
+}
+
+// The same pipeline on a block of `height` rows of a taller frame (one rank's share when a host-resident frame is
+// split over the GPUs of a node: bands are independent, no communication).  When a side is not the frame border the
+// RGB row just outside the block is read from host memory next to it (rgb - pitch / rgb + height * pitch).
+extern "C" int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsigned char *edge, int width, int height, int channels,
+                                                int mode, int tile_rows, int host_buffers_pinned, int top_is_border, int bottom_is_border,
+                                                double *seconds)
+{
     GH_REQUIRE(width >= 0 && height >= 0, "negative size");
     GH_REQUIRE(channels == 3 || channels == 4, "streamed pipeline takes RGB8 or RGBA8");
     GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
@@ -61,8 +71,10 @@ extern "C" int gh_gray_sobel_streamed_host(const unsigned char *rgb, unsigned ch
 
     Ring r;
     if (!host_buffers_pinned) {
-        GH_HIP_TRY(hipHostRegister(const_cast<unsigned char *>(rgb), row_in * height, hipHostRegisterDefault));
-        r.reg_in = true; r.reg_in_ptr = rgb;
+        const unsigned char *reg0 = rgb - (top_is_border ? 0 : row_in);
+        const size_t reg_rows = (size_t)height + (top_is_border ? 0 : 1) + (bottom_is_border ? 0 : 1);
+        GH_HIP_TRY(hipHostRegister(const_cast<unsigned char *>(reg0), row_in * reg_rows, hipHostRegisterDefault));
+        r.reg_in = true; r.reg_in_ptr = reg0;
         GH_HIP_TRY(hipHostRegister(edge, row_out * height, hipHostRegisterDefault));
         r.reg_out = true; r.reg_out_ptr = edge;
     }
@@ -82,7 +94,7 @@ extern "C" int gh_gray_sobel_streamed_host(const unsigned char *rgb, unsigned ch
         const int slot = k % NSLOT;
         const int y0 = k * tile_rows;
         const int rows = (y0 + tile_rows <= height) ? tile_rows : height - y0;
-        const bool top = y0 == 0, bot = y0 + rows == height;
+        const bool top = y0 == 0 && top_is_border, bot = y0 + rows == height && bottom_is_border;
         // the slot's previous tenant (tile k - NSLOT) must have been computed (input buffer free) and downloaded (output free)
         if (k >= NSLOT) {
             GH_HIP_TRY(hipStreamWaitEvent(r.s_in, r.computed[slot], 0));

@@ -79,6 +79,27 @@ def gray_sobel_streamed(rgb: np.ndarray, edge: np.ndarray, tile_rows: int = 4096
     return secs.value
 
 
+def gray_sobel_streamed_rows(frame_rows: np.ndarray, edge: np.ndarray, y0: int, y1: int, tile_rows: int = 4096, mode: int = MODE_IEEE,
+                             pinned: bool = False, first_row_of_frame: int = 0, frame_height: int | None = None) -> float:
+    """One rank's share of a streamed frame: `frame_rows` is a host (n, w, c) array holding frame rows
+    [first_row_of_frame, first_row_of_frame + n), which must include rows y0-1 and y1 unless they lie outside the frame
+    (frame_height rows, default: the array is the whole frame).  Rows [y0, y1) are processed into edge ((y1-y0, w) host)."""
+    n, w, c = frame_rows.shape
+    fh = (first_row_of_frame + n) if frame_height is None else frame_height
+    rows = y1 - y0
+    if edge.shape != (rows, w):
+        raise GrayHipError("edge must be (y1 - y0, w)")
+    top, bot = y0 == 0, y1 == fh
+    lo, hi = y0 - first_row_of_frame, y1 - first_row_of_frame
+    if lo - (0 if top else 1) < 0 or hi + (0 if bot else 1) > n:
+        raise GrayHipError("frame_rows does not hold the halo rows of [y0, y1)")
+    secs = C.c_double(0.0)
+    base = _host_ptr(frame_rows, False) + lo * w * c
+    check(abi.load().gh_gray_sobel_streamed_rows_host(base, _host_ptr(edge, True), w, rows, c, mode, tile_rows, int(pinned), int(top), int(bot),
+                                                      C.byref(secs)), "gray_sobel_streamed_rows")
+    return secs.value
+
+
 def sum_rgb(rgb: np.ndarray) -> list[int]:
     """Exact per-channel sums of an RGB8 frame (old/parallel_avg_pixel.c restated)."""
     s = (C.c_uint64 * 3)()

@@ -22,40 +22,69 @@ def main():
     a = ap.parse_args()
     import numpy as np
     import torch
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # N GPUs: the frame's rows are split over the ranks; bands are independent, so the only collective is the
+        # timing barrier (gloo).  Launch: python -m torch.distributed.run --nproc-per-node N tools/bench_streamed.py ...
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
     pkg = importlib.import_module("openmp-parallel-computing_amd")
     api = pkg.hostapi
-    api.init(0)
+    api.init(local % max(torch.cuda.device_count(), 1))
     w, h = a.width, a.height
+    y0, y1 = pkg.sharding.row_partition(h, world)[rank]
+    lo, hi = max(0, y0 - 1), min(h, y1 + 1)              # this rank's rows plus the halo rows that exist
     t0 = time.time()
-    rgb_t = torch.empty((h, w, 3), dtype=torch.uint8).pin_memory()
-    edge_t = torch.empty((h, w), dtype=torch.uint8).pin_memory()
+    rgb_t = torch.empty((hi - lo, w, 3), dtype=torch.uint8).pin_memory()
+    edge_t = torch.empty((y1 - y0, w), dtype=torch.uint8).pin_memory()
     rgb, edge = rgb_t.numpy(), edge_t.numpy()
-    # synthetic frame: SplitMix64 stream, generated tile by tile (seed = tile index + 1) like SURVEY.md 8(d)
+    # synthetic frame: SplitMix64 stream, generated tile by tile (seed = tile index + 1) like SURVEY.md 8(d); a rank
+    # generates the tiles that overlap its rows, so neighbouring ranks agree on their shared halo rows
     from oracle import pyoracle as O
-    for k, y0 in enumerate(range(0, h, a.tile_rows)):
-        y1 = min(h, y0 + a.tile_rows)
-        rgb[y0:y1] = O.frame_rand(w, y1 - y0, 3, seed=k + 1)
+    for k in range(lo // a.tile_rows, (hi - 1) // a.tile_rows + 1):
+        t_lo, t_hi = k * a.tile_rows, min(h, (k + 1) * a.tile_rows)
+        tile = O.frame_rand(w, t_hi - t_lo, 3, seed=k + 1)
+        s_lo, s_hi = max(lo, t_lo), min(hi, t_hi)
+        rgb[s_lo - lo:s_hi - lo] = tile[s_lo - t_lo:s_hi - t_lo]
     t_gen = time.time() - t0
     best = None
     for _ in range(a.reps):
-        secs = api.gray_sobel_streamed(rgb, edge, tile_rows=a.tile_rows, pinned=True)
+        if world > 1:
+            dist.barrier()
+        t_a = time.perf_counter()
+        api.gray_sobel_streamed_rows(rgb, edge, y0, y1, tile_rows=a.tile_rows, pinned=True, first_row_of_frame=lo, frame_height=h)
+        secs = time.perf_counter() - t_a
+        if world > 1:
+            t = torch.tensor([secs], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
         best = secs if best is None else min(best, secs)
-    # parity: rows around every band boundary (and the frame top) against the oracle
+    # parity: rows around every band boundary of this rank (and its first rows) against the oracle
     ok = True
-    for y0 in list(range(0, h, a.tile_rows)):
-        lo, hi = max(0, y0 - a.check_rows // 2), min(h, y0 + a.check_rows // 2)
-        src_lo, src_hi = max(0, lo - 1), min(h, hi + 1)
-        want = O.sobel(O.gray_to_plane(np.ascontiguousarray(rgb[src_lo:src_hi]), 0))
-        got = edge[lo:hi]
-        ok = ok and np.array_equal(got[1:-1], want[lo - src_lo + 1: hi - src_lo - 1])   # rows with both neighbours in the slice
+    for b0 in list(range(y0, y1, a.tile_rows)):
+        c_lo, c_hi = max(y0, b0 - a.check_rows // 2), min(y1, b0 + a.check_rows // 2)
+        src_lo, src_hi = max(lo, c_lo - 1), min(hi, c_hi + 1)
+        want = O.sobel(O.gray_to_plane(np.ascontiguousarray(rgb[src_lo - lo:src_hi - lo]), 0))
+        got = edge[c_lo - y0:c_hi - y0]
+        ok = ok and np.array_equal(got[1:-1], want[c_lo - src_lo + 1: c_hi - src_lo - 1])   # rows with both neighbours in the slice
+    if world > 1:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
     npix = w * h
-    out = {"config": f"{w}x{h} RGB8 streamed in bands of {a.tile_rows} rows, 3 hipStreams, pinned host memory",
-           "Mpixels/s": round(npix / best / 1e6, 1), "seconds": round(best, 4),
-           "h2d_GB/s": round(3 * npix / best / 1e9, 2), "d2h_GB/s": round(npix / best / 1e9, 2),
-           "pcie_total_GB/s": round(4 * npix / best / 1e9, 2), "frame_generation_s": round(t_gen, 1),
-           "parity_spot_check": "ok" if ok else "MISMATCH"}
-    print(json.dumps(out))
+    if rank == 0:
+        out = {"config": f"{w}x{h} RGB8 streamed in bands of {a.tile_rows} rows, 3 hipStreams per GPU, pinned host memory, {world} GPU(s), "
+                         "rows split over the ranks, no communication",
+               "n_gpus": world, "Mpixels/s": round(npix / best / 1e6, 1), "seconds": round(best, 4),
+               "h2d_GB/s": round(3 * npix / best / 1e9, 2), "d2h_GB/s": round(npix / best / 1e9, 2),
+               "pcie_total_GB/s": round(4 * npix / best / 1e9, 2), "frame_generation_s": round(t_gen, 1),
+               "parity_spot_check": "ok" if ok else "MISMATCH"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
     return 0 if ok else 3
+
 
 
 if __name__ == "__main__":
