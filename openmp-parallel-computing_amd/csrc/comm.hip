@@ -5,8 +5,9 @@
 // a contiguous block of rows, and one exchange step -- the row above and the row below a shard come from the
 // neighbouring ranks.  At 8 GPUs a 16384^2 frame leaves ~25 us of kernel time per shard, so the
 // host cost of the exchange decides the scaling curve; this file issues the two send/recv pairs as one ncclGroup on a
-// side stream straight from C++ (no Python between the calls) and overlaps them with the interior rows, which do not
-// depend on the halo.
+// high-priority side stream straight from C++ (no Python between the calls) and overlaps them either with the interior
+// rows of the same frame (gh_sharded_*_step_dev) or, for a stream of frames, with the whole shard of an earlier frame
+// (gh_sharded_*_step_pipelined_dev: the halo of frame k+2 travels while frame k runs as one launch).
 //
 // RCCL is loaded with dlopen at gh_comm_init time: the single-GPU library, the CLIs and the drop-in boundary do not
 // depend on librccl.so.
@@ -129,12 +130,19 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
     }
     // high priority: its own hardware queue (a plain second stream may be mapped onto the caller's queue, which would
     // serialise the exchange with the shard kernels), and the small exchange kernel is not stuck behind a full grid
-    int prio_least = 0, prio_greatest = 0;
-    GH_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    GH_HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest));
-    GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-    GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
-    for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
+    const int rc = [&]() -> int {
+        int prio_least = 0, prio_greatest = 0;
+        GH_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        GH_HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest));
+        GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+        GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
+        for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
+        return GH_OK;
+    }();
+    if (rc != GH_OK) {
+        gh_comm_destroy(c);       // releases whatever was created (the error text of the failed call is kept)
+        return rc;
+    }
     *out = c;
     return GH_OK;
 }
