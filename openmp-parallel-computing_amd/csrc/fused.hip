@@ -6,11 +6,11 @@
 // luma (rows above/below a band, pixels left/right of a strip) is recomputed from RGB, which is also the
 // zero-communication alternative to exchanging luma halo rows between shards.
 //
-//   k_fused_dma         default for RGB8, width >= 1024: strip streaming (stream_core.h) with an LDS row ring filled by
+//   k_fused_dma         default for RGB8 / RGBA8, width >= 1024: strip streaming (stream_core.h) with an LDS row ring filled by
 //                       LDS-DMA (global_load_lds_dwordx4, three rows deep): a wave's 3 KiB of a row lands lane-linear
 //                       in LDS, every lane reads back its 16 consecutive pixels (48 B), converts to luma in f32 and
 //                       feeds the f32 Sobel row step directly (no byte round trip).  GH_FUSED_DMA=0 turns it off.
-//   k_fused_stream      RGBA8 / narrow frames: the same strip streaming, rows staged through registers
+//   k_fused_stream      narrow frames (or GH_FUSED_DMA=0): the same strip streaming, rows staged through registers
 //                       (coalesced dwordx4 loads -> ds_write -> ds_read de-interleave).
 //   k_gray_sobel_fused  the LDS-tile form (sobel_tile.h); GH_FUSED_IMPL=tile
 #include "sobel_tile.h"
@@ -225,7 +225,7 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 }
 
 
-// ---- LDS-DMA form (RGB8, width >= 1024): rows go HBM -> LDS directly (global_load_lds_dwordx4), D rows deep -----------
+// ---- LDS-DMA form (RGB8 / RGBA8, width >= 1024): rows go HBM -> LDS directly (global_load_lds_dwordx4), D rows deep -----------
 // The register-staged kernel above holds C rows of loads in VGPRs (24 + 8 registers at C = 2) and pays three ds_write per
 // row to de-interleave them.  Here a wave owns a ring of D row slots in LDS; one row = three 1 KiB LDS-DMA pieces + one
 // dword piece carrying the two strip-halo pixels (lanes 0 and 1 fetch the dword left / right of the strip).  The DMA
@@ -234,15 +234,16 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 // the only loads younger than row i's are those of rows i+1 .. i+D-1 (4 instructions each); output stores in between
 // only make the count conservative.  The last strip of a row is shifted left to end at the frame edge (all strips are
 // full; the overlap is recomputed and stored twice with identical bytes), so no lane of a DMA piece is ever masked.
-template <int MODE, int D, int SP>
+template <int MODE, int D, int SP, int CH = 3>
 __global__ __launch_bounds__(stream_core::BLOCK)
 void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
                  int zero_bot)
 {
     using namespace stream_core;
-    constexpr int SLOT = STRIP_PX * 3 + 16;                      // one strip row + the halo dword pair
+    constexpr int SLOT = STRIP_PX * CH + 16;                      // one strip row + the halo dword pair
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
-    static_assert(5 * (D - 1) <= 60, "vmcnt is 6 bits");
+    constexpr int NLD = CH + 1;                                   // DMA pieces per row: CH x 1 KiB + the halo dword
+    static_assert((NLD + 1) * (D - 1) <= 60, "vmcnt is 6 bits");
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -261,10 +262,10 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     const int nrows = min(R, rows - y0) + 2;                     // input rows of this band (clipped to the frame) incl. halo
     const int nch = (nrows + CHK - 1) / CHK;
     const f32x2 half2 = half2_reg();
-    const uint32_t voff = (uint32_t)xw * 3u + (uint32_t)lane * 16u;            // byte offset of this lane's piece in a row
+    const uint32_t voff = (uint32_t)xw * CH + (uint32_t)lane * 16u;            // byte offset of this lane's piece in a row
     // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its bytes 1..3),
     //              lane 1 -> the 4 bytes after the strip's last byte (pixel xw+1024 = its bytes 0..2); clamped when outside
-    uint32_t hoff = lane == 0 ? (uint32_t)xw * 3u - 4u : (uint32_t)(xw + STRIP_PX) * 3u;
+    uint32_t hoff = lane == 0 ? (uint32_t)xw * CH - 4u : (uint32_t)(xw + STRIP_PX) * CH;   // RGBA: the left dword IS pixel xw-1
     if ((lane == 0 && xw == 0) || (lane != 0 && xw + STRIP_PX >= w)) hoff = 0;
     const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
 
@@ -273,10 +274,10 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
 
     auto issue_row = [&](int i, int slot) {
         const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
-        const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * 3);
+        const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * CH);
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        glds_row3k(dst, rowb, voff);
-        if (lane < 2) glds_dword(dst + STRIP_PX * 3, rowb, hoff);
+        if (CH == 3) glds_row3k(dst, rowb, voff); else glds_row4k(dst, rowb, voff);
+        if (lane < 2) glds_dword(dst + STRIP_PX * CH, rowb, hoff);
     };
     // nrows >= 3 > D - 1 for D <= 3; for deeper rings the prologue may run past a very short band: clamp_row keeps it readable
 #pragma unroll
@@ -294,19 +295,20 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
                 if (i + D - 1 < nrows) {
                     issue_row(i + D - 1, (j + D - 1) % D);
-                    if (steady) wait_vm<5 * (D - 1)>(); else wait_vm<4 * (D - 1)>();
+                    if (steady) wait_vm<(NLD + 1) * (D - 1)>(); else wait_vm<NLD * (D - 1)>();
                 } else {
                     wait_vm<0>();
                 }
                 const uint8_t *slotp = &ring[wave][j % D][0];
-                const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 48 * lane);
-                const uint4 u0 = sr[0], u1 = sr[1], u2 = sr[2];
-                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * 3);
-                const uint32_t wv[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
-                const uint32_t hw = lane == 0 ? (hh.x >> 8) : hh.y;
+                const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 16 * CH * lane);
+                uint32_t wv[4 * CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
+                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
+                const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : hh.y;
                 uint4 out;
-                if (SP >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[11]);   // probe: no compute
-                else out = (j & 1) ? fused_row<MODE, 3, 1>(st, wv, hw, lane, half2) : fused_row<MODE, 3, 0>(st, wv, hw, lane, half2);
+                if (SP >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
+                else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
                 if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
                     const int y = y0 + i - 2;
                     if (x == 0) out.x &= 0xffffff00u;
@@ -388,7 +390,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
         //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
         //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
         int dma = GH_TUNE_INT("GH_FUSED_DMA", -1);         // ring depth D (0 = register-staged kernel, -1 = auto)
-        if (dma != 0 && channels == 3 && width >= stream_core::STRIP_PX) {
+        if (dma != 0 && width >= stream_core::STRIP_PX) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
@@ -411,7 +413,10 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             const size_t pad = (size_t)pad_kb * 1024;
 #define GH_FD(D_, W_)                                                                                                      \
             do {                                                                                                           \
-                if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
+                if (channels == 4) {                                                                                       \
+                    if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, (W_) % 10, 4><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
+                    else k_fused_dma<GH_MODE_IEEE, D_, (W_) % 10, 4><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
+                } else if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);          \
                 else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
             } while (0)
             if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }

@@ -316,6 +316,21 @@ __device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *row
                  : "v"(voff), "s"(rowb), "s"(lds_slot)
                  : "memory");
 }
+__device__ __forceinline__ void glds_row4k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rowb), "s"(lds_slot)
+                 : "memory");
+}
 __device__ __forceinline__ void glds_row1k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
 {
     uint32_t keep;

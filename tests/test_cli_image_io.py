@@ -143,3 +143,27 @@ def test_pnm_and_garbage(tmp_path):
     assert p.returncode == 1
     (tmp_path / "junk.bin").write_bytes(os.urandom(64))
     assert subprocess.run([TOOL, "decode", str(tmp_path / "junk.bin"), str(tmp_path / "x.raw")], capture_output=True).returncode == 1
+
+
+def test_malformed_inputs_are_rejected_not_crashed(tmp_path):
+    """Truncated / corrupted JPEG and PNG files (the CLI sits behind an upload service in the reference's wrappers):
+    the decoder may refuse them (exit 1) or decode what is there (exit 0), but never crash.  The ASan/UBSan version of
+    this loop is tools/fuzz_codec.py."""
+    import random
+    rnd = random.Random(11)
+    jpg = open(os.path.join(GOLDEN, "test.jpg"), "rb").read()
+    png_path = tmp_path / "seed.png"
+    encode(np.random.RandomState(2).randint(0, 256, size=(40, 56, 3), dtype=np.uint8), png_path, tmp_path)
+    png = png_path.read_bytes()
+    for k in range(40):
+        src = jpg if k % 2 == 0 else png
+        m = bytearray(src)
+        if k % 4 < 2:
+            m = m[: rnd.randrange(1, len(m))]
+        else:
+            for _ in range(rnd.randrange(1, 8)):
+                m[rnd.randrange(0, min(len(m), 1024))] = rnd.randrange(256)
+        f = tmp_path / "m.bin"
+        f.write_bytes(bytes(m))
+        p = subprocess.run([TOOL, "decode", str(f), str(tmp_path / "x.raw")], capture_output=True, timeout=60)
+        assert p.returncode in (0, 1), (k, p.returncode, p.stderr[-300:])

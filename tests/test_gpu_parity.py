@@ -215,12 +215,12 @@ def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     tests/conftest.py sets GH_TUNE_DYNAMIC so that the library re-reads the knobs on every launch."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
-    for (w, h) in ((2064, 150), (1024, 67), (4096, 3)):
-        img = oracle.frame_rand(w, h, 3, seed=w + h)
+    for (w, h, ch) in ((2064, 150, 3), (1024, 67, 3), (4096, 3, 3), (2064, 131, 4), (1024, 2, 4)):
+        img = oracle.frame_rand(w, h, ch, seed=w + h)
         d = dev(torch_mod, img)
         for mode in (0, 1):
             want = oracle.sobel(oracle.gray_to_plane(img, mode))
-            assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), (knobs, w, h, mode)
+            assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), (knobs, w, h, ch, mode)
 
 
 @pytest.mark.parametrize("knobs", [{"GH_SOBEL_DMA": "0"}, {"GH_SOBEL_DMA": "2"}, {"GH_SOBEL_DMA": "3"}, {"GH_SOBEL_DMA": "4"}, {"GH_SOBEL_DMA": "6"},

@@ -19,9 +19,11 @@ torch.manual_seed(1)
 rgb = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda")
 plane = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda")
 out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda") if a.op == "fused4" else None
 out3 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") if a.op == "conv" else None
 ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (lambda: api.sobel(plane, out=out), 2),
        "gray": (lambda: api.gray_to_plane(rgb, 0, out=out), 4),
+       "fused4": (lambda: api.gray_sobel_fused(rgba, 0, out=out), 5),
        "conv": (lambda: api.conv3x3(rgb, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16, out=out3), 6)}
 fn, bpp = ops[a.op]
 variants = [("base", {})]

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Mutation fuzzing of the CLIs' image decoders (PNG all colour types / bit depths / Adam7, baseline + progressive JPEG,
+PNM) under AddressSanitizer + UBSan.  Host code only, no GPU.  Developer tool:
+
+    g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Iopenmp-parallel-computing_amd/csrc \
+        openmp-parallel-computing_amd/csrc/cli/{imgtool,image_io,jpeg_decode}.cpp -lz -o /tmp/fuzz/imgtool_asan
+    python3 tools/fuzz_codec.py [mutations per seed] [path of the instrumented tool]
+
+A decoder may reject an input (exit 1) but must never crash, read out of bounds or hit undefined behaviour.
+Round 1: 5,000+ mutated inputs, no finding.  tests/test_cli_image_io.py runs a short version against bin/gh_imgtool."""
+import os, random, subprocess, sys, zlib, struct
+random.seed(7)
+tool = sys.argv[2] if len(sys.argv) > 2 else "/tmp/fuzz/imgtool_asan"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs("/tmp/fuzz", exist_ok=True)
+seeds = {}
+seeds["test.jpg"] = open(os.path.join(ROOT, "tests", "golden", "test.jpg"), "rb").read()
+# more JPEGs (progressive, other samplings) when a directory of them is given: data inputs only
+for p in sorted(__import__("glob").glob(os.path.join(os.environ.get("GH_FUZZ_JPEG_DIR", "/nonexistent"), "*.jpg"))):
+    seeds[os.path.basename(p)] = open(p, "rb").read()
+# small PNGs of several types, made with our own encoder through the tool (encode) + handmade variants
+import numpy as np
+def png_chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+def make_png(w, h, ctype, depth, interlace=0, palette=None):
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = ch * depth
+    raw = b""
+    rng = np.random.default_rng(w * 31 + h + ctype)
+    if interlace == 0:
+        rowbytes = (w * bpp + 7) // 8
+        for y in range(h): raw += bytes([rng.integers(0, 5)]) + rng.integers(0, 256, rowbytes, dtype=np.uint8).tobytes()
+    else:
+        for (x0, y0, dx, dy) in ((0,0,8,8),(4,0,8,8),(0,4,4,8),(2,0,4,4),(0,2,2,4),(1,0,2,2),(0,1,1,2)):
+            pw, ph = (w - x0 + dx - 1) // dx, (h - y0 + dy - 1) // dy
+            if pw <= 0 or ph <= 0: continue
+            rowbytes = (pw * bpp + 7) // 8
+            for y in range(ph): raw += bytes([rng.integers(0, 5)]) + rng.integers(0, 256, rowbytes, dtype=np.uint8).tobytes()
+    out = b"\x89PNG\r\n\x1a\n" + png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if ctype == 3: out += png_chunk(b"PLTE", bytes(range(256)) * 3) + png_chunk(b"tRNS", bytes(range(0, 256, 2)))
+    out += png_chunk(b"IDAT", zlib.compress(raw, 6)) + png_chunk(b"IEND", b"")
+    return out
+for (ct, d) in ((0,1),(0,2),(0,4),(0,8),(0,16),(2,8),(2,16),(3,1),(3,2),(3,4),(3,8),(4,8),(4,16),(6,8),(6,16)):
+    for il in (0, 1):
+        seeds[f"png_c{ct}_d{d}_i{il}"] = make_png(37, 19, ct, d, il)
+seeds["pnm"] = b"P6\n5 4\n255\n" + bytes(range(60))
+seeds["pgm"] = b"P5\n# c\n7 3\n255\n" + bytes(range(21))
+bad = 0; runs = 0
+def run(data, tag):
+    global bad, runs
+    open("/tmp/fuzz/in.bin", "wb").write(data)
+    r = subprocess.run([tool, "decode", "/tmp/fuzz/in.bin", "/tmp/fuzz/out.raw"], capture_output=True, timeout=60)
+    runs += 1
+    if r.returncode not in (0, 1) or b"AddressSanitizer" in r.stderr or b"runtime error" in r.stderr:
+        bad += 1
+        print("FAIL", tag, r.returncode, r.stderr[-600:].decode(errors="replace"))
+# 1. clean seeds decode
+for n, d in seeds.items(): run(d, "clean " + n)
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for n, d in seeds.items():
+    big = len(d) > 200000
+    k = max(4, iters // (6 if big else 1))
+    for i in range(k):
+        m = bytearray(d)
+        mode = i % 4
+        if mode == 0:   # truncate
+            m = m[: random.randrange(1, len(m))]
+        elif mode == 1: # flip a few bytes, biased to the header
+            for _ in range(random.randrange(1, 6)):
+                pos = random.randrange(0, min(len(m), 2048)) if random.random() < 0.7 else random.randrange(len(m))
+                m[pos] = random.randrange(256)
+        elif mode == 2: # splice garbage
+            pos = random.randrange(len(m)); m[pos:pos + random.randrange(1, 64)] = os.urandom(random.randrange(1, 64))
+        else:           # set a 16/32-bit field to an extreme value
+            pos = random.randrange(0, min(len(m) - 4, 1024)); m[pos:pos + 4] = random.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x00", b"\x7f\xff\xff\xff", b"\x00\x00\xff\xff"])
+        run(bytes(m), f"{n} mut{i} mode{mode}")
+print("runs", runs, "bad", bad)
