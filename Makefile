@@ -23,7 +23,7 @@ HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h $(CSRC)/stream_core.h
 
 CXX      ?= g++
-CXXFLAGS := -O2 -std=c++17 -Wall -Iinclude -I$(CSRC)
+CXXFLAGS := -O2 -std=c++17 -Wall -pthread -Iinclude -I$(CSRC)
 
 all: lib cli oracle
 

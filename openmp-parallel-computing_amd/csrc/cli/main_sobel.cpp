@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 
 #include "grayhip.h"
 #include "image_io.h"
@@ -15,6 +16,10 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Uso: %s <input_img> <output_img.png> [passaggi_kernel]\n", argv[0]);
         return 1;
     }
+    // HIP start-up (~0.1 s: runtime, context, code object) overlaps the image decode; a failure is reported by the
+    // first real call below, which finds the library already (un)initialised
+    std::thread warm([] { const char *e = getenv("GRAYHIP_DEVICE"); (void)gh_init(e ? atoi(e) : 0); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
     GhImage img;
     std::string err;
     if (!gh_image_load(argv[1], img, err)) {

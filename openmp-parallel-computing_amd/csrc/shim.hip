@@ -20,6 +20,7 @@ thread_local char g_err[768] = "";
 std::once_flag g_init_once;
 int g_init_rc = GH_OK;
 int g_device = -1;
+char g_init_err[768] = "";     // why initialisation failed, for threads other than the one that tried
 
 // grow-only device scratch for the host-pointer entry points (caller threads are serialised)
 struct Scratch {
@@ -97,8 +98,17 @@ int gh_ensure_init()
     std::call_once(g_init_once, [] {
         const char *e = getenv("GRAYHIP_DEVICE");
         g_init_rc = do_init(e ? atoi(e) : 0);
+        if (g_init_rc != GH_OK) snprintf(g_init_err, sizeof g_init_err, "%s", g_err);
     });
-    if (g_init_rc != GH_OK && g_err[0] == 0) gh_set_error(g_init_rc, "HIP initialisation failed earlier in this process");
+    if (g_init_rc != GH_OK && g_err[0] == 0)
+        gh_set_error(g_init_rc, "%s", g_init_err[0] ? g_init_err : "HIP initialisation failed earlier in this process");
+    // hipSetDevice is per host thread: a thread other than the one that initialised the library would otherwise launch on
+    // device 0 (the CLIs initialise HIP on a helper thread while the main thread decodes the input image)
+    static thread_local int t_device = -1;
+    if (g_init_rc == GH_OK && t_device != g_device) {
+        if (hipSetDevice(g_device) != hipSuccess) return gh_set_error(GH_ERR_HIP, "hipSetDevice(%d) failed on this thread", g_device);
+        t_device = g_device;
+    }
     return g_init_rc;
 }
 
@@ -107,7 +117,11 @@ extern "C" {
 int gh_init(int device)
 {
     bool first = false;
-    std::call_once(g_init_once, [&] { first = true; g_init_rc = do_init(device); });
+    std::call_once(g_init_once, [&] {
+        first = true;
+        g_init_rc = do_init(device);
+        if (g_init_rc != GH_OK) snprintf(g_init_err, sizeof g_init_err, "%s", g_err);
+    });
     if (first || g_init_rc != GH_OK) return g_init_rc;
     if (device != g_device) {   // re-target an already initialised process
         int rc = do_init(device);

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Wall-time anatomy of the drop-in CLI on the GPU box (developer tool): whole process vs decode / HIP start-up / encode.
+set -e
+IMG=${1:-tests/golden/test.jpg}
+OUT=/tmp/cli_out.png
+TIMEFORMAT="  wall %R s (user %U sys %S)"
+for i in 1 2 3; do echo "bin/grayscale:"; time bin/grayscale "$IMG" $OUT 1; done
+for lv in 1 3 6; do for th in 1 32; do echo "bin/grayscale GH_PNG_LEVEL=$lv GH_PNG_THREADS=$th:"; time GH_PNG_LEVEL=$lv GH_PNG_THREADS=$th bin/grayscale "$IMG" $OUT 1; ls -l $OUT | cut -d" " -f5; done; done
+for i in 1 2; do echo "bin/grayscale_sobel:"; time bin/grayscale_sobel "$IMG" $OUT 1; done
+echo "decode only (gh_imgtool):"; time bin/gh_imgtool decode "$IMG" /tmp/cli_raw.bin
+python3 - <<'PY'
+import ctypes, time, os
+t0 = time.perf_counter()
+lib = ctypes.CDLL(os.path.join("openmp-parallel-computing_amd", "lib", "libgrayhip.so"))
+t1 = time.perf_counter()
+rc = lib.gh_init(0)
+t2 = time.perf_counter()
+print(f"dlopen libgrayhip {1e3*(t1-t0):.0f} ms, gh_init (hipInit + context + first kernel module load) {1e3*(t2-t1):.0f} ms, rc={rc}")
+PY
