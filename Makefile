@@ -37,27 +37,34 @@ $(LIB): $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -ldl -o $@
 
 CLI_COMMON := $(CSRC)/cli/image_io.cpp $(CSRC)/cli/jpeg_decode.cpp
-cli: bin/grayscale bin/grayscale_sobel bin/gh_imgtool
+CLI_CORE   := $(CSRC)/cli/cli_core.cpp $(CSRC)/cli/cli_core.h
+cli: bin/grayscale bin/grayscale_sobel bin/grayhipd bin/gh_imgtool
 
 bin/gh_imgtool: $(CSRC)/cli/imgtool.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h
 	@mkdir -p bin
 	$(CXX) $(CXXFLAGS) $(CSRC)/cli/imgtool.cpp $(CLI_COMMON) -lz -o $@
 
-bin/grayscale: $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h $(LIB)
+bin/grayscale: $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) $(CLI_CORE) $(CSRC)/cli/image_io.h $(LIB)
 	@mkdir -p bin
-	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_gray.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_gray.cpp $(CSRC)/cli/cli_core.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
 	    -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
 
-bin/grayscale_sobel: $(CSRC)/cli/main_sobel.cpp $(CLI_COMMON) $(CSRC)/cli/image_io.h $(LIB)
+bin/grayscale_sobel: $(CSRC)/cli/main_sobel.cpp $(CLI_COMMON) $(CLI_CORE) $(CSRC)/cli/image_io.h $(LIB)
 	@mkdir -p bin
-	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_sobel.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_sobel.cpp $(CSRC)/cli/cli_core.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
+	    -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+# resident server: the CLIs' work in one warm process (GRAYHIP_SERVER=<socket> turns the CLIs into its clients)
+bin/grayhipd: $(CSRC)/cli/main_server.cpp $(CLI_COMMON) $(CLI_CORE) $(CSRC)/cli/image_io.h $(LIB)
+	@mkdir -p bin
+	$(CXX) $(CXXFLAGS) $(CSRC)/cli/main_server.cpp $(CSRC)/cli/cli_core.cpp $(CLI_COMMON) -L$(LIBDIR) -lgrayhip -lz \
 	    -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(HIP_OBJS) $(LIB) bin/grayscale bin/grayscale_sobel
+	rm -f $(HIP_OBJS) $(LIB) bin/grayscale bin/grayscale_sobel bin/grayhipd
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib cli oracle clean

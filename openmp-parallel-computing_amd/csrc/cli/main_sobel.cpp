@@ -2,13 +2,10 @@
 //   grayscale_sobel <input_img> <output_img.png> [passes]
 // Per pass: luma -> 3x3 Sobel -> edge replicated into R,G,B (alpha untouched), all on MI355X.
 // As in the reference, a failed PNG save only prints a message and the exit code stays 0.
+// GRAYHIP_SERVER=<socket>: served by a resident bin/grayhipd when one listens there (see main_gray.cpp).
 #include <cstdio>
-#include <cstdlib>
-#include <string>
-#include <thread>
 
-#include "grayhip.h"
-#include "image_io.h"
+#include "cli_core.h"
 
 int main(int argc, char *argv[])
 {
@@ -16,28 +13,10 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Uso: %s <input_img> <output_img.png> [passaggi_kernel]\n", argv[0]);
         return 1;
     }
-    // HIP start-up (~0.1 s: runtime, context, code object) overlaps the image decode; a failure is reported by the
-    // first real call below, which finds the library already (un)initialised
-    std::thread warm([] { const char *e = getenv("GRAYHIP_DEVICE"); (void)gh_init(e ? atoi(e) : 0); });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
-    GhImage img;
-    std::string err;
-    if (!gh_image_load(argv[1], img, err)) {
-        fprintf(stderr, "Errore caricando immagine \"%s\"\n", argv[1]);
-        if (getenv("GRAYHIP_VERBOSE")) fprintf(stderr, "grayhip: %s\n", err.c_str());
-        return 1;
-    }
-    int passes = (argc >= 4) ? atoi(argv[3]) : 1;
-    if (passes < 1) passes = 1;
-
-    double secs = 0.0;
-    if (gh_pipeline_gray_sobel_host(img.pixels.data(), img.width, img.height, img.channels, passes, gh_default_mode(), &secs) != GH_OK) {
-        fprintf(stderr, "grayhip: %s\n", gh_last_error());
-        return 1;
-    }
-    printf("Compute kernel (grayscale + sobel) ×%d: %.4f s\n", passes, secs);
-
-    if (!gh_image_write_png(argv[2], img.width, img.height, img.channels, img.pixels.data(), err))
-        fprintf(stderr, "Errore nel salvataggio di \"%s\"\n", argv[2]);
-    return 0;
+    const char *passes = argc >= 4 ? argv[3] : nullptr;
+    GhCliResult r;
+    if (!gh_cli_try_server(GH_CLI_SOBEL, argv[1], argv[2], passes, r)) r = gh_cli_run(GH_CLI_SOBEL, argv[0], argv[1], argv[2], passes);
+    fputs(r.out.c_str(), stdout);
+    fputs(r.err.c_str(), stderr);
+    return r.exit_code;
 }

@@ -115,3 +115,104 @@ def test_flask_style_caller(tmp_path, jpg_crop):
     result = subprocess.run([GRAY, str(src), str(out), "2"], capture_output=True, env=env)
     assert result.returncode == 0 and out.exists()
     assert np.array_equal(np.asarray(Image.open(out))[..., 0], np.asarray(Image.open(out))[..., 2])
+
+
+# ---- the resident server (bin/grayhipd) and the CLIs as its clients ----------------------------------------
+
+SERVER = os.path.join(ROOT, "bin", "grayhipd")
+
+
+def _field(s: bytes) -> bytes:
+    return str(len(s)).encode() + b"\n" + s
+
+
+def test_client_speaks_the_wire_protocol_and_falls_back(tmp_path):
+    """No GPU needed: a stand-in server checks what the CLI sends and feeds it a canned reply; with no server at the
+    socket path the CLI does the work itself (and, on a box without a GPU, fails loudly as before)."""
+    import socket
+    import threading
+    path = str(tmp_path / "s.sock")
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind(path)
+    srv.listen(1)
+    seen = {}
+
+    def serve():
+        c, _ = srv.accept()
+        f = c.makefile("rb")
+        seen["head"] = f.readline()
+        fields = []
+        for _ in range(4):
+            n = int(f.readline())
+            fields.append(f.read(n))
+        seen["fields"] = fields
+        c.sendall(b"7\n" + _field("Compute kernel ×3: 0.0001 s\n".encode()) + _field(b"a warning\n"))
+        c.close()
+
+    t = threading.Thread(target=serve)
+    t.start()
+    os.makedirs(tmp_path / "wd", exist_ok=True)
+    e = dict(os.environ, GRAYHIP_SERVER=path, GRAYHIP_MODE="fma")
+    p = subprocess.run([GRAY, "in.jpg", "/abs/out.png", "3"], capture_output=True, text=True, env=e, cwd=tmp_path / "wd")
+    t.join()
+    srv.close()
+    assert seen["head"] == b"GRAYHIP1 gray 4\n"
+    assert seen["fields"] == [str(tmp_path / "wd" / "in.jpg").encode(), b"/abs/out.png", b"3", b"fma"]     # paths made absolute
+    assert (p.returncode, p.stdout, p.stderr) == (7, "Compute kernel ×3: 0.0001 s\n", "a warning\n")
+    # nobody listening: in-process path, same contract as without GRAYHIP_SERVER
+    p = subprocess.run([GRAY, tmp_path / "missing.png", tmp_path / "o.png"], capture_output=True, text=True,
+                       env=dict(os.environ, GRAYHIP_SERVER=str(tmp_path / "nobody.sock")))
+    assert p.returncode == 1 and p.stderr == "Errore caricando immagine\n"
+
+
+@pytest.mark.gpu
+def test_resident_server_serves_the_unchanged_cli(tmp_path, jpg_crop):
+    """bin/grayhipd + GRAYHIP_SERVER: same stdout / stderr / exit codes and the same output pixels as the in-process CLI,
+    also under concurrent clients and with the arithmetic mode of each client."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    sock = str(tmp_path / "gh.sock")
+    srv = subprocess.Popen([SERVER, sock], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        assert srv.stdout.readline().startswith("grayhipd: serving on ")
+        src = tmp_path / "in.png"
+        Image.fromarray(jpg_crop["rgb"]).save(src)
+        env = {"GRAYHIP_SERVER": sock}
+        for exe, line in ((GRAY, r"^Compute kernel ×2: \d+\.\d{4} s\n$"), (SOBEL, r"^Compute kernel \(grayscale \+ sobel\) ×2: \d+\.\d{4} s\n$")):
+            local, served = tmp_path / "local.png", tmp_path / "served.png"
+            a = run(exe, src, local, 2)
+            b = run(exe, src, served, 2, env=env)
+            assert a.returncode == b.returncode == 0 and b.stderr == "" and re.match(line, b.stdout), (b.stdout, b.stderr)
+            assert np.array_equal(np.asarray(Image.open(local)), np.asarray(Image.open(served)))
+        # per-client mode
+        outs = {}
+        for mode in ("ieee", "fma"):
+            o = tmp_path / f"{mode}.png"
+            assert run(GRAY, src, o, env={**env, "GRAYHIP_MODE": mode}).returncode == 0
+            outs[mode] = np.asarray(Image.open(o))
+            lo = tmp_path / f"{mode}_local.png"
+            assert run(GRAY, src, lo, env={"GRAYHIP_MODE": mode}).returncode == 0
+            assert np.array_equal(outs[mode], np.asarray(Image.open(lo)))
+        # error paths keep their texts and codes
+        p = run(GRAY, tmp_path / "nope.png", tmp_path / "o.png", env=env)
+        assert (p.returncode, p.stdout, p.stderr) == (1, "", "Errore caricando immagine\n")
+        p = run(SOBEL, src, tmp_path / "no_such_dir" / "o.png", env=env)
+        assert p.returncode == 0 and p.stderr.startswith("Errore nel salvataggio di")
+        # concurrent clients
+        def one(i):
+            o = tmp_path / f"c{i}.png"
+            r = run(SOBEL if i % 2 else GRAY, src, o, 1, env=env)
+            return r.returncode, o
+        with ThreadPoolExecutor(8) as ex:
+            res = list(ex.map(one, range(16)))
+        ref = {0: np.asarray(Image.open(res[0][1])), 1: np.asarray(Image.open(res[1][1]))}
+        for i, (rc, o) in enumerate(res):
+            assert rc == 0 and np.array_equal(np.asarray(Image.open(o)), ref[i % 2])
+        # what it is for: per-call wall time without HIP start-up
+        t0 = time.perf_counter(); run(GRAY, src, tmp_path / "t.png", env=env); served_s = time.perf_counter() - t0
+        t0 = time.perf_counter(); run(GRAY, src, tmp_path / "t.png"); local_s = time.perf_counter() - t0
+        print(f"served {served_s*1e3:.0f} ms vs in-process {local_s*1e3:.0f} ms")
+    finally:
+        srv.terminate()
+        srv.wait(timeout=20)
+    assert not os.path.exists(sock)          # the server removes its socket on SIGTERM

@@ -17,3 +17,9 @@ rc = lib.gh_init(0)
 t2 = time.perf_counter()
 print(f"dlopen libgrayhip {1e3*(t1-t0):.0f} ms, gh_init (hipInit + context + first kernel module load) {1e3*(t2-t1):.0f} ms, rc={rc}")
 PY
+echo "--- resident server ---"
+bin/grayhipd /tmp/gh_timing.sock > /tmp/grayhipd.log 2>&1 &
+SRV=$!
+for i in $(seq 1 50); do [ -S /tmp/gh_timing.sock ] && break; sleep 0.1; done
+for i in 1 2 3 4; do echo "bin/grayscale via grayhipd:"; time GRAYHIP_SERVER=/tmp/gh_timing.sock bin/grayscale "$IMG" $OUT 1; done
+kill $SRV; wait $SRV 2>/dev/null || true
