@@ -2,6 +2,7 @@
 oracle, the compiled reference's known answers and the reference's golden image.  Bit-exact for
 every uint8 output and every integer sum -- there is no floating-point tolerance anywhere."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -565,3 +566,29 @@ def test_streamed_row_blocks_equal_whole_frame(pkg, oracle):
     part = np.zeros((y1 - y0, w), dtype=np.uint8)
     pkg.hostapi.gray_sobel_streamed_rows(local, part, y0, y1, tile_rows=64, first_row_of_frame=y0 - 1, frame_height=h)
     assert np.array_equal(part, want[y0:y1])
+
+
+def test_random_geometry_sweep(pkg, oracle, torch_mod):
+    """Seeded sweep over frame geometries around the kernels' internal boundaries (1024-px strips, 64/32/16-row bands, the
+    shifted last strip, one- and two-row frames) for the plane Sobel, the fused RGB8 / RGBA8 kernels and their band forms."""
+    rnd = np.random.RandomState(20261004)
+    shapes = [(1024, 1), (1024, 64), (1024, 65), (2048, 66), (1040, 63), (3072, 17), (16, 1), (32, 2), (1008, 40)]
+    for _ in range(int(os.environ.get("GH_SWEEP", "24"))):
+        w = 16 * int(rnd.randint(1, 330))
+        h = int(rnd.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 66, 67, 127, 129, 130, 200]))
+        shapes.append((w, h))
+    for (w, h) in shapes:
+        for ch in (3, 4):
+            img = oracle.frame_rand(w, h, ch, seed=w * 3 + h + ch)
+            d = dev(torch_mod, img)
+            mode = (w // 16 + h) & 1
+            luma = oracle.gray_to_plane(img, mode)
+            want = oracle.sobel(luma)
+            assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), ("fused", w, h, ch, mode)
+            if ch == 3:
+                assert np.array_equal(pkg.hostapi.sobel(dev(torch_mod, luma)).cpu().numpy(), want), ("sobel", w, h)
+            if h >= 3:      # a middle band: first and last row of the frame act as halo rows
+                got = torch_mod.empty((h - 2, w), dtype=torch_mod.uint8, device="cuda")
+                pkg.hostapi.gray_sobel_fused_rows(d, got, h - 2, mode, False, False)
+                # rows 1..h-2 of the whole-frame result are exactly what a band with real halo rows must produce
+                assert np.array_equal(got.cpu().numpy(), want[1:h - 1]), ("band", w, h, ch)
