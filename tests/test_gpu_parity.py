@@ -592,3 +592,32 @@ def test_random_geometry_sweep(pkg, oracle, torch_mod):
                 pkg.hostapi.gray_sobel_fused_rows(d, got, h - 2, mode, False, False)
                 # rows 1..h-2 of the whole-frame result are exactly what a band with real halo rows must produce
                 assert np.array_equal(got.cpu().numpy(), want[1:h - 1]), ("band", w, h, ch)
+
+
+def test_device_entry_points_are_graph_capturable(pkg, oracle, torch_mod):
+    """INTEGRATION.md promises that the *_dev entry points are asynchronous, allocation-free and capturable: record
+    gray -> Sobel and the fused kernel into one hipGraph, replay it on fresh output buffers."""
+    t = torch_mod
+    w, h = 2064, 70
+    img = oracle.frame_rand(w, h, 3, seed=3)
+    want = oracle.sobel(oracle.gray_to_plane(img, 0))
+    d = dev(t, img)
+    luma = t.zeros((h, w), dtype=t.uint8, device="cuda")
+    e1 = t.zeros((h, w), dtype=t.uint8, device="cuda")
+    e2 = t.zeros((h, w), dtype=t.uint8, device="cuda")
+    s = t.cuda.Stream()
+    s.wait_stream(t.cuda.current_stream())
+    with t.cuda.stream(s):
+        pkg.hostapi.gray_to_plane(d, 0, out=luma); pkg.hostapi.sobel(luma, out=e1); pkg.hostapi.gray_sobel_fused(d, 0, out=e2)   # warm-up
+    t.cuda.current_stream().wait_stream(s)
+    t.cuda.synchronize()
+    g = t.cuda.CUDAGraph()
+    with t.cuda.graph(g, stream=s):
+        pkg.hostapi.gray_to_plane(d, 0, out=luma)
+        pkg.hostapi.sobel(luma, out=e1)
+        pkg.hostapi.gray_sobel_fused(d, 0, out=e2)
+    for _ in range(3):
+        luma.zero_(); e1.zero_(); e2.zero_()
+        g.replay()
+        t.cuda.synchronize()
+        assert np.array_equal(e1.cpu().numpy(), want) and np.array_equal(e2.cpu().numpy(), want)
