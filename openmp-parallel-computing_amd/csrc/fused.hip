@@ -276,7 +276,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * CH);
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        if (CH == 3) glds_row3k(dst, rowb, voff); else glds_row4k(dst, rowb, voff);
+        if (CH == 3) glds_row3k<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, rowb, voff); else glds_row4k(dst, rowb, voff);
         if (lane < 2) glds_dword(dst + STRIP_PX * CH, rowb, hoff);
     };
     // nrows >= 3 > D - 1 for D <= 3; for deeper rings the prologue may run past a very short band: clamp_row keeps it readable
@@ -307,17 +307,17 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
                 const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
                 const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : hh.y;
                 uint4 out;
-                if (SP >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
+                if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
                 else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
                 if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
                     const int y = y0 + i - 2;
                     if (x == 0) out.x &= 0xffffff00u;
                     if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                     if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                    if (SP >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
-                        store_strip_p<SP % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
+                    if ((SP % 100) >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
+                        store_strip_p<(SP % 100) % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
                     else
-                        store_strip_p<SP % 10>(edge + (size_t)y * w + xw, lane, out);
+                        store_strip_p<(SP % 100) % 10>(edge + (size_t)y * w + xw, lane, out);
                 }
             }
         }
@@ -420,7 +420,8 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
                 else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
             } while (0)
             if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }
-            else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else GH_FD(2, 2); }
+            else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else if (sp == 102) GH_FD(2, 102); else if (sp == 302) GH_FD(2, 302);
+                                 else if (sp == 402) GH_FD(2, 402); else if (sp == 502) GH_FD(2, 502); else GH_FD(2, 2); }
             else { if (sp == 0) GH_FD(3, 0); else if (sp == 1) GH_FD(3, 1); else if (sp == 10) GH_FD(3, 10); else if (sp == 12) GH_FD(3, 12); else if (sp == 22) GH_FD(3, 22); else GH_FD(3, 2); }
 #undef GH_FD
             GH_LAUNCH_CHECK();

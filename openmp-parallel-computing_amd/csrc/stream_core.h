@@ -302,20 +302,29 @@ __device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int
 // ---- LDS-DMA (global_load_lds_*) helpers of the ring kernels (fused.hip k_fused_dma, sobel.hip k_sobel_dma) -------------
 // hipcc does not count asm memory operations: the kernels place their own s_waitcnt vmcnt(N) (wait_vm).  M0 carries the
 // wave-uniform LDS destination; each lane's data lands at M0 + instruction offset + lane * size.
+// LP: cache policy of the DMA loads (0 default, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt); nt measured best, as for register loads
+#define GH_GLDS3(POL)                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\t"                                                              \
+                 "s_mov_b32 m0, %3\n\t"                                                              \
+                 "s_nop 0\n\t"                                                                       \
+                 "global_load_lds_dwordx4 %1, %2" POL "\n\t"                                         \
+                 "global_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"                             \
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t"                             \
+                 "s_mov_b32 m0, %0"                                                                   \
+                 : "=&s"(keep)                                                                        \
+                 : "v"(voff), "s"(rowb), "s"(lds_slot)                                                \
+                 : "memory")
+template <int LP = 1>
 __device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_slot)
-                 : "memory");
+    if (LP == 0) GH_GLDS3("");
+    else if (LP == 2) GH_GLDS3(" sc1");
+    else if (LP == 3) GH_GLDS3(" sc0 sc1");
+    else if (LP == 4) GH_GLDS3(" sc1 nt");
+    else GH_GLDS3(" nt");
 }
+#undef GH_GLDS3
 __device__ __forceinline__ void glds_row4k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
 {
     uint32_t keep;
