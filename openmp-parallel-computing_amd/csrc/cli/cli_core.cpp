@@ -30,7 +30,7 @@ std::string fmt(const char *f, ...)
 
 }  // namespace
 
-GhCliResult gh_cli_run(GhCliKind kind, const char *prog, const char *in_path, const char *out_path, const char *passes_arg)
+GhCliResult gh_cli_run(GhCliKind kind, const char *prog, const char *in_path, const char *out_path, const char *passes_arg, int mode)
 {
     GhCliResult r;
     // HIP start-up (~0.1 s: runtime, context, code object) overlaps the image decode; a failure is reported by the first
@@ -49,8 +49,8 @@ GhCliResult gh_cli_run(GhCliKind kind, const char *prog, const char *in_path, co
     if (passes < 1) passes = 1;
     double secs = 0.0;
     const int rc = kind == GH_CLI_GRAY
-                       ? gh_gray_passes_host(img.pixels.data(), img.width, img.height, img.channels, passes, gh_default_mode(), &secs)
-                       : gh_pipeline_gray_sobel_host(img.pixels.data(), img.width, img.height, img.channels, passes, gh_default_mode(), &secs);
+                       ? gh_gray_passes_host(img.pixels.data(), img.width, img.height, img.channels, passes, mode, &secs)
+                       : gh_pipeline_gray_sobel_host(img.pixels.data(), img.width, img.height, img.channels, passes, mode, &secs);
     if (rc != GH_OK) {
         r.err = fmt("grayhip: %s\n", gh_last_error());   // no CPU fallback: a GPU failure is an error exit
         r.exit_code = 1;

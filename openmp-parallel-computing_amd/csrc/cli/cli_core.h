@@ -17,7 +17,8 @@ struct GhCliResult {
 
 // monolithic/src/main.c:14-49 (gray) / main_with_sobel.c:16-92 (sobel) with the kernels on the GPU.
 // prog = argv[0] for the usage text; paths as given on the command line.
-GhCliResult gh_cli_run(GhCliKind kind, const char *prog, const char *in_path, const char *out_path, const char *passes_arg);
+// mode: GH_MODE_IEEE / GH_MODE_FMA (the CLIs pass gh_default_mode(), i.e. GRAYHIP_MODE; the server passes its client's).
+GhCliResult gh_cli_run(GhCliKind kind, const char *prog, const char *in_path, const char *out_path, const char *passes_arg, int mode);
 
 // Client side of the resident server: if the environment names a server socket (GRAYHIP_SERVER) and a server answers
 // there, the request is served by it and true is returned with `res` filled; otherwise false (run in-process).

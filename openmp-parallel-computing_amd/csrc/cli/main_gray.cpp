@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "cli_core.h"
+#include "grayhip.h"
 
 int main(int argc, char *argv[])
 {
@@ -17,7 +18,7 @@ int main(int argc, char *argv[])
     }
     const char *passes = argc >= 4 ? argv[3] : nullptr;
     GhCliResult r;
-    if (!gh_cli_try_server(GH_CLI_GRAY, argv[1], argv[2], passes, r)) r = gh_cli_run(GH_CLI_GRAY, argv[0], argv[1], argv[2], passes);
+    if (!gh_cli_try_server(GH_CLI_GRAY, argv[1], argv[2], passes, r)) r = gh_cli_run(GH_CLI_GRAY, argv[0], argv[1], argv[2], passes, gh_default_mode());
     fputs(r.out.c_str(), stdout);
     fputs(r.err.c_str(), stderr);
     return r.exit_code;

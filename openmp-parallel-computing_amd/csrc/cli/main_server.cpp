@@ -16,7 +16,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <thread>
 
@@ -28,7 +27,6 @@ namespace {
 std::atomic<bool> g_stop{false};
 int g_listen_fd = -1;
 std::string g_path;
-std::mutex g_mode_mu;      // GRAYHIP_MODE is process-wide state of the library's default: requests with a mode are serialised
 
 void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) shutdown(g_listen_fd, SHUT_RDWR); }
 
@@ -43,15 +41,10 @@ void serve(int fd)
         gh_wire_recv_field(fd, in, 1 << 16) && gh_wire_recv_field(fd, out, 1 << 16) && gh_wire_recv_field(fd, passes, 32) &&
         gh_wire_recv_field(fd, mode, 16)) {
         const GhCliKind kind = strcmp(kind_s, "sobel") == 0 ? GH_CLI_SOBEL : GH_CLI_GRAY;
-        if (!mode.empty()) {
-            std::lock_guard<std::mutex> lk(g_mode_mu);
-            setenv("GRAYHIP_MODE", mode.c_str(), 1);
-            r = gh_cli_run(kind, "grayhipd", in.c_str(), out.c_str(), passes.c_str());
-            unsetenv("GRAYHIP_MODE");
-        } else {
-            std::lock_guard<std::mutex> lk(g_mode_mu);       // keeps a concurrent setenv away from gh_default_mode()
-            r = gh_cli_run(kind, "grayhipd", in.c_str(), out.c_str(), passes.c_str());
-        }
+        // the client's GRAYHIP_MODE travels with the request; requests run concurrently (decode / encode in parallel,
+        // the GPU section is serialised inside libgrayhip)
+        const int m = mode.empty() ? gh_default_mode() : ((mode == "fma" || mode == "FMA") ? GH_MODE_FMA : GH_MODE_IEEE);
+        r = gh_cli_run(kind, "grayhipd", in.c_str(), out.c_str(), passes.c_str(), m);
     } else {
         r.err = "grayhipd: malformed request\n";
     }
