@@ -16,11 +16,12 @@ from conftest import GOLDEN, ROOT
 
 GRAY = os.path.join(ROOT, "bin", "grayscale")
 SOBEL = os.path.join(ROOT, "bin", "grayscale_sobel")
+SERVER = os.path.join(ROOT, "bin", "grayhipd")
 
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    if not (os.access(GRAY, os.X_OK) and os.access(SOBEL, os.X_OK)):
+    if not (os.access(GRAY, os.X_OK) and os.access(SOBEL, os.X_OK) and os.access(SERVER, os.X_OK)):
         subprocess.run(["make", "-C", ROOT, "cli"], check=True, capture_output=True)
 
 
@@ -118,9 +119,6 @@ def test_flask_style_caller(tmp_path, jpg_crop):
 
 
 # ---- the resident server (bin/grayhipd) and the CLIs as its clients ----------------------------------------
-
-SERVER = os.path.join(ROOT, "bin", "grayhipd")
-
 
 def _field(s: bytes) -> bytes:
     return str(len(s)).encode() + b"\n" + s
