@@ -142,6 +142,11 @@ def cpu_baseline(width: int, sample_rows: int) -> dict:
 
 def main() -> int:
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON: libraries print banners to file descriptor 1 (RCCL's version block when a
+    # communicator is created, gloo's connection notes), so everything else is sent to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -461,7 +466,8 @@ def main() -> int:
             except Exception as exc:
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "unavailable",
                                        "sample": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if world > 1:
         dist.barrier()
