@@ -350,6 +350,23 @@ __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__res
     compute_tile(tile, edge, w, rows, x0, y0, zero_top, zero_bot);
 }
 
+// launch arguments of k_fused_dma, and the channel / mode dispatch
+struct DmaLaunch {
+    const uint8_t *rgb; uint8_t *edge; int width, rows, groups_x; BandPlan plan; int zt, zb, channels, mode; unsigned grid; size_t pad; hipStream_t s;
+};
+template <int D, int SP>
+void launch_fused_dma(const DmaLaunch &L)
+{
+    const unsigned b = stream_core::BLOCK;
+    if (L.channels == 4) {
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+    } else {
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP, 3><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+    }
+}
+
 }  // namespace
 
 extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode,
@@ -396,7 +413,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
                 rd = nb64 >= GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
             }
-            const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // output store policy: 0 default, 1 sc1, 2 nt
+            const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;
             // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
             const BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
@@ -411,19 +428,34 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             }
             if (pad_kb < 0) pad_kb = 0;
             const size_t pad = (size_t)pad_kb * 1024;
-#define GH_FD(D_, W_)                                                                                                      \
-            do {                                                                                                           \
-                if (channels == 4) {                                                                                       \
-                    if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, (W_) % 10, 4><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);   \
-                    else k_fused_dma<GH_MODE_IEEE, D_, (W_) % 10, 4><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
-                } else if (mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);          \
-                else k_fused_dma<GH_MODE_IEEE, D_, W_><<<g, b, pad, s>>>(rgb, edge, width, rows, groups_x, plan, zt, zb);                      \
-            } while (0)
-            if (dma == 4) { if (sp == 0) GH_FD(4, 0); else if (sp == 1) GH_FD(4, 1); else GH_FD(4, 2); }
-            else if (dma == 2) { if (sp == 0) GH_FD(2, 0); else if (sp == 1) GH_FD(2, 1); else if (sp == 102) GH_FD(2, 102); else if (sp == 302) GH_FD(2, 302);
-                                 else if (sp == 402) GH_FD(2, 402); else if (sp == 502) GH_FD(2, 502); else GH_FD(2, 2); }
-            else { if (sp == 0) GH_FD(3, 0); else if (sp == 1) GH_FD(3, 1); else if (sp == 10) GH_FD(3, 10); else if (sp == 12) GH_FD(3, 12); else if (sp == 22) GH_FD(3, 22); else GH_FD(3, 2); }
-#undef GH_FD
+            const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s};
+            if (sp == 2) {                      // production: nontemporal output stores
+                if (dma == 2) launch_fused_dma<2, 2>(L);
+                else if (dma == 4) launch_fused_dma<4, 2>(L);
+                else launch_fused_dma<3, 2>(L);
+            } else {
+#ifdef GH_ENABLE_PROBES
+                // SP = 100 * (load policy + 1) + 10 * probe + store policy -- see k_fused_dma; RGB8 only
+                switch (dma * 1000 + sp) {
+                case 2000: launch_fused_dma<2, 0>(L); break;
+                case 2001: launch_fused_dma<2, 1>(L); break;
+                case 2102: launch_fused_dma<2, 102>(L); break;
+                case 2302: launch_fused_dma<2, 302>(L); break;
+                case 2402: launch_fused_dma<2, 402>(L); break;
+                case 2502: launch_fused_dma<2, 502>(L); break;
+                case 3000: launch_fused_dma<3, 0>(L); break;
+                case 3001: launch_fused_dma<3, 1>(L); break;
+                case 3010: launch_fused_dma<3, 10>(L); break;
+                case 3012: launch_fused_dma<3, 12>(L); break;
+                case 3022: launch_fused_dma<3, 22>(L); break;
+                case 4000: launch_fused_dma<4, 0>(L); break;
+                case 4001: launch_fused_dma<4, 1>(L); break;
+                default: GH_REQUIRE(false, "unknown GH_FUSED_DMA / GH_FUSED_DMA_ST probe combination");
+                }
+#else
+                GH_REQUIRE(false, "GH_FUSED_DMA_ST probes need a library built with -DGH_ENABLE_PROBES (make HIPFLAGS_EXTRA=-DGH_ENABLE_PROBES)");
+#endif
+            }
             GH_LAUNCH_CHECK();
             return GH_OK;
         }

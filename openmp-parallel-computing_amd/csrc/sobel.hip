@@ -318,7 +318,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
             if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt
+#ifdef GH_ENABLE_PROBES
+            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt (wrong results)
+#endif
             else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);

@@ -3,6 +3,8 @@
 
 usage: ab_fused.py [--op fused|sobel|gray] [--w W] [--h H] [--rounds N] "NAME=K1:V1,K2:V2" ...
 Each variant is a set of environment knobs (GH_TUNE_DYNAMIC makes the library re-read them per launch).
+The probe variants (GH_FUSED_DMA_ST other than 2, GH_SOBEL_DMA=13) exist only in a library built with
+`make lib HIPFLAGS_EXTRA=-DGH_ENABLE_PROBES`.
 """
 import argparse, importlib, os, sys, hashlib, statistics
 os.environ["GH_TUNE_DYNAMIC"] = "1"
