@@ -247,14 +247,21 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
     int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
     if (xw >= w) return;
     if (xw + STRIP_PX > w) xw = w - STRIP_PX;                    // last strip: shifted left, overlaps its neighbour
     const int x = xw + 16 * lane;
     // band plan: n[0] bands of R[0] rows, then n[1] of R[1], then bands of R[2] (shorter bands last: a short drain)
+    if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    if (gy_i >= plan.n[0]) {
+    if (plan.order >= 1000) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
+        y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
+        R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
+        if (gy_i == plan.bands - 1) R = rows - y0;        // the last band takes what is left
+        if (y0 >= rows) return;
+    } else if (gy_i >= plan.n[0]) {
         const int g1 = gy_i - plan.n[0];
         R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
         if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
@@ -416,8 +423,10 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;
             // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
-            const BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
+            BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
                                                  GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 0), plan.bands, groups_x);
+            
             GH_REQUIRE((long long)groups_x * plan.bands < (1ll << 31), "frame too large for one launch");
             const unsigned g = (unsigned)((long long)groups_x * plan.bands);
             int pad_kb = GH_TUNE_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU

@@ -120,13 +120,20 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
     int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
     if (xw >= w) return;
     if (xw + STRIP_PX > w) xw = w - STRIP_PX;
     const int x = xw + 16 * lane;
+    if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    if (gy_i >= plan.n[0]) {
+    if (plan.order >= 1000) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
+        y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
+        R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
+        if (gy_i == plan.bands - 1) R = rows - y0;        // the last band takes what is left
+        if (y0 >= rows) return;
+    } else if (gy_i >= plan.n[0]) {
         const int g1 = gy_i - plan.n[0];
         R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
         if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
@@ -304,7 +311,10 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         // but a shard must still give every CU a few workgroups.  Power-of-two heights only: band starts aligned to
         // 2^k rows measured 10-15 % faster than 30 / 34 / 48 / 60-row bands in the no-compute strip-copy probe.
         int R = r_env;
-        if (R != 16 && R != 32 && R != 64) {
+        const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
+        const bool use_dma = dma && core == 1 && width >= stream_core::STRIP_PX;
+        // the LDS-DMA kernel takes any band height (tuning knob); the register-staged one is instantiated for 16 / 32 / 64
+        if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
             // measured on MI355X (16384-wide planes, tools/ab_fused.py --op sobel): 64-row bands win from 8192 rows up
             // (66-67 % of 8 TB/s vs 59-61 % for 32 / 16), 32 at 4096 rows, 16 below
@@ -313,9 +323,10 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
-        const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
-        if (dma && core == 1 && width >= stream_core::STRIP_PX) {
-            const stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+        if (use_dma) {
+            stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 0), plan.bands, groups_x);
+            
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
             if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES

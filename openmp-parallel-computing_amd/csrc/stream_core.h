@@ -372,6 +372,7 @@ struct BandPlan {
     int R[3];
     int y[3];
     int bands;      // total
+    int order;      // workgroup -> (band, column group) mapping, see band_of_block(); 0 = band-major (default)
 };
 inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
 {
@@ -388,6 +389,46 @@ inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
     const int left2 = rows - p.y[2];
     p.bands = n0 + n1 + (left2 + R2 - 1) / R2;
     return p;
+}
+
+// blockIdx -> (column group gx, band gy).  `order` packs the tuning parameters of the mapping (GH_FUSED_DMA_ORDER /
+// GH_SOBEL_ORDER, decimal digits "ASCM"):
+//   M (units)     0: column group fastest (a band's workgroups are dispatched together); 2: band fastest; 4: XCD-major --
+//                 workgroup b belongs to XCD b % 8, and every XCD walks its own contiguous run of (band, column) pairs
+//   C (tens)      column group rotated by C * band
+//   S (hundreds)  bands visited with stride {1, 37, 3, 5, 7, 11, 13, 17, 19, 23}[S] (a permutation when co-prime to the count)
+//   A (thousands) 1: band heights alternate R-1, R+1 (band starts alternate between even and odd rows)
+// Which mapping is fastest is decided by how the rows that are in flight at the same time spread over the memory
+// channels; measured on MI355X: see DESIGN.md.
+__device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk, int groups_x, int &gx, int &gy)
+{
+    const unsigned bands = (unsigned)plan.bands, total = bands * (unsigned)groups_x;
+    const int M = plan.order % 10, C = (plan.order / 10) % 10, S = (plan.order / 100) % 10;
+    if (M == 4) {                       // XCD-major: the workgroups of XCD x, in dispatch order, walk one contiguous run of the default order
+        const unsigned per = (total + 7) / 8, x = blk % 8, i = blk / 8;
+        blk = x * per + i;
+        if (blk >= total) { gx = 0; gy = -1; return; }      // only when total is not a multiple of 8: surplus slots idle
+    }
+    if (M == 2) { gy = (int)(blk % bands); gx = (int)(blk / bands); }
+    else { gx = (int)(blk % (unsigned)groups_x); gy = (int)(blk / (unsigned)groups_x); }
+    if (C) gx = (gx + C * gy) % groups_x;
+    if (S) {
+        const unsigned strides[10] = {1, 37, 3, 5, 7, 11, 13, 17, 19, 23};
+        gy = (int)(((unsigned long long)gy * strides[S]) % bands);
+    }
+}
+
+// host side: drop the parts of a mapping request that would not be a permutation of the (band, column) pairs
+inline int sanitize_order(int order, int bands, int groups_x)
+{
+    if (order <= 0) return 0;
+    int M = order % 10, C = (order / 10) % 10, S = (order / 100) % 10, A = (order / 1000) % 10;
+    const unsigned strides[10] = {1, 37, 3, 5, 7, 11, 13, 17, 19, 23};
+    if (M != 0 && M != 2 && M != 4) M = 0;
+    if (M == 4 && ((long long)bands * groups_x) % 8 != 0) M = 0;
+    if (S && (unsigned)bands % strides[S] == 0) S = 0;
+    if (A > 1 || bands < 2) A = 0;
+    return A * 1000 + S * 100 + C * 10 + M;
 }
 
 template <int N>
