@@ -256,7 +256,8 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     // band plan: n[0] bands of R[0] rows, then n[1] of R[1], then bands of R[2] (shorter bands last: a short drain)
     if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    if (plan.order >= 1000) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
+    stagger_start(plan, gy_i);
+    if (plan.order / 1000 == 1) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
         y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
         R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
         if (gy_i == plan.bands - 1) R = rows - y0;        // the last band takes what is left
@@ -411,6 +412,8 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
         // LDS-DMA ring kernel.  Tuning found on MI355X (tools/ab_fused.py, 16384-wide frames):
         //  * band height 64 is the sweet spot whenever it still gives every CU a workgroup (69-73 % of 8 TB/s for 4096 ..
         //    16384-row frames); 32- and 128-row bands are 5-15 % slower at the same frame, 16-row bands pay 12.5 % halo rows;
+        //  * band-per-XCD dispatch order (order 6: XCD x owns the bands k = x mod 8 with all their column groups) is 0.5-2.5 %
+        //    faster than the plain band-major order on every frame shape and shard size tried (16384^2: 72.9 % vs 72.1 %);
         //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
         //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
         int dma = GH_TUNE_INT("GH_FUSED_DMA", -1);         // ring depth D (0 = register-staged kernel, -1 = auto)
@@ -425,10 +428,10 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
             BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
                                                  GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 0), plan.bands, groups_x);
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 6), plan.bands, groups_x);
             
-            GH_REQUIRE((long long)groups_x * plan.bands < (1ll << 31), "frame too large for one launch");
-            const unsigned g = (unsigned)((long long)groups_x * plan.bands);
+            GH_REQUIRE(stream_core::plan_grid(plan, groups_x) < (1ll << 31), "frame too large for one launch");
+            const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);
             int pad_kb = GH_TUNE_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU
             if (dma < 0) {
                 const bool big = g > 2u * GH_NUM_CU;

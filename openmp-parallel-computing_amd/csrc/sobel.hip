@@ -128,7 +128,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     const int x = xw + 16 * lane;
     if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    if (plan.order >= 1000) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
+    stagger_start(plan, gy_i);
+    if (plan.order / 1000 == 1) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
         y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
         R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
         if (gy_i == plan.bands - 1) R = rows - y0;        // the last band takes what is left
@@ -326,6 +327,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         if (use_dma) {
             stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
             plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 0), plan.bands, groups_x);
+            const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
             
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
             if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);

@@ -394,7 +394,8 @@ inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
 // blockIdx -> (column group gx, band gy).  `order` packs the tuning parameters of the mapping (GH_FUSED_DMA_ORDER /
 // GH_SOBEL_ORDER, decimal digits "ASCM"):
 //   M (units)     0: column group fastest (a band's workgroups are dispatched together); 2: band fastest; 4: XCD-major --
-//                 workgroup b belongs to XCD b % 8, and every XCD walks its own contiguous run of (band, column) pairs
+//                 workgroup b belongs to XCD b % 8, and every XCD walks its own contiguous run of (band, column) pairs;
+//                 6: band-per-XCD -- XCD x owns the bands k = x (mod 8) with all their column groups
 //   C (tens)      column group rotated by C * band
 //   S (hundreds)  bands visited with stride {1, 37, 3, 5, 7, 11, 13, 17, 19, 23}[S] (a permutation when co-prime to the count)
 //   A (thousands) 1: band heights alternate R-1, R+1 (band starts alternate between even and odd rows)
@@ -409,7 +410,12 @@ __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk
         blk = x * per + i;
         if (blk >= total) { gx = 0; gy = -1; return; }      // only when total is not a multiple of 8: surplus slots idle
     }
-    if (M == 2) { gy = (int)(blk % bands); gx = (int)(blk / bands); }
+    if (M == 6) {                       // band-per-XCD: XCD x (= blk % 8) owns the bands k = x (mod 8), all column groups of each
+        const unsigned x = blk % 8, i = blk / 8;
+        gy = (int)(8 * (i / (unsigned)groups_x) + x);
+        gx = (int)(i % (unsigned)groups_x);
+        if ((unsigned)gy >= bands) gy = -1;
+    } else if (M == 2) { gy = (int)(blk % bands); gx = (int)(blk / bands); }
     else { gx = (int)(blk % (unsigned)groups_x); gy = (int)(blk / (unsigned)groups_x); }
     if (C) gx = (gx + C * gy) % groups_x;
     if (S) {
@@ -418,16 +424,34 @@ __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk
     }
 }
 
+// Start stagger probe (order thousands digit A = 2..9): band gy waits (gy * 5 % 8) * 2^(A-2) * ~0.13 us before its first
+// load, so that the bands do not walk their rows in lockstep.
+__device__ __forceinline__ void stagger_start(const BandPlan &plan, int gy)
+{
+    const int A = (plan.order / 1000) % 10;
+    if (A < 2) return;
+    const int n = ((gy * 5) & 7) << (A - 2);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);       // 4 * 64 cycles ~ 0.13 us
+}
+
+// host side: workgroups to launch for a plan (the band-per-XCD order pads the band count to a multiple of 8: surplus
+// workgroups find gy < 0 and exit)
+inline long long plan_grid(const BandPlan &plan, int groups_x)
+{
+    const long long bands = (plan.order % 10 == 6) ? ((plan.bands + 7) / 8) * 8ll : plan.bands;
+    return bands * groups_x;
+}
+
 // host side: drop the parts of a mapping request that would not be a permutation of the (band, column) pairs
 inline int sanitize_order(int order, int bands, int groups_x)
 {
     if (order <= 0) return 0;
     int M = order % 10, C = (order / 10) % 10, S = (order / 100) % 10, A = (order / 1000) % 10;
     const unsigned strides[10] = {1, 37, 3, 5, 7, 11, 13, 17, 19, 23};
-    if (M != 0 && M != 2 && M != 4) M = 0;
+    if (M != 0 && M != 2 && M != 4 && M != 6) M = 0;
     if (M == 4 && ((long long)bands * groups_x) % 8 != 0) M = 0;
     if (S && (unsigned)bands % strides[S] == 0) S = 0;
-    if (A > 1 || bands < 2) A = 0;
+    if (bands < 2) A = 0;          // A = 1: alternating heights; A = 2..9: start stagger probe (see stagger_start)
     return A * 1000 + S * 100 + C * 10 + M;
 }
 
