@@ -395,7 +395,8 @@ inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
 // GH_SOBEL_ORDER, decimal digits "ASCM"):
 //   M (units)     0: column group fastest (a band's workgroups are dispatched together); 2: band fastest; 4: XCD-major --
 //                 workgroup b belongs to XCD b % 8, and every XCD walks its own contiguous run of (band, column) pairs;
-//                 6: band-per-XCD -- XCD x owns the bands k = x (mod 8) with all their column groups
+//                 6: band-per-XCD -- XCD x owns the bands k = x (mod 8) with all their column groups; 8: the same with
+//                 pairs of neighbouring bands
 //   C (tens)      column group rotated by C * band
 //   S (hundreds)  bands visited with stride {1, 37, 3, 5, 7, 11, 13, 17, 19, 23}[S] (a permutation when co-prime to the count)
 //   A (thousands) 1: band heights alternate R-1, R+1 (band starts alternate between even and odd rows)
@@ -413,6 +414,11 @@ __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk
     if (M == 6) {                       // band-per-XCD: XCD x (= blk % 8) owns the bands k = x (mod 8), all column groups of each
         const unsigned x = blk % 8, i = blk / 8;
         gy = (int)(8 * (i / (unsigned)groups_x) + x);
+        gx = (int)(i % (unsigned)groups_x);
+        if ((unsigned)gy >= bands) gy = -1;
+    } else if (M == 8) {                // pairs-per-XCD: XCD x owns the band pairs p = x (mod 8), i.e. bands 2p and 2p + 1
+        const unsigned x = blk % 8, i = blk / 8, bi = i / (unsigned)groups_x;
+        gy = (int)(2 * (8 * (bi >> 1) + x) + (bi & 1));
         gx = (int)(i % (unsigned)groups_x);
         if ((unsigned)gy >= bands) gy = -1;
     } else if (M == 2) { gy = (int)(blk % bands); gx = (int)(blk / bands); }
@@ -438,7 +444,8 @@ __device__ __forceinline__ void stagger_start(const BandPlan &plan, int gy)
 // workgroups find gy < 0 and exit)
 inline long long plan_grid(const BandPlan &plan, int groups_x)
 {
-    const long long bands = (plan.order % 10 == 6) ? ((plan.bands + 7) / 8) * 8ll : plan.bands;
+    const int M = plan.order % 10;
+    const long long bands = M == 6 ? ((plan.bands + 7) / 8) * 8ll : (M == 8 ? ((plan.bands + 15) / 16) * 16ll : plan.bands);
     return bands * groups_x;
 }
 
@@ -448,7 +455,7 @@ inline int sanitize_order(int order, int bands, int groups_x)
     if (order <= 0) return 0;
     int M = order % 10, C = (order / 10) % 10, S = (order / 100) % 10, A = (order / 1000) % 10;
     const unsigned strides[10] = {1, 37, 3, 5, 7, 11, 13, 17, 19, 23};
-    if (M != 0 && M != 2 && M != 4 && M != 6) M = 0;
+    if (M != 0 && M != 2 && M != 4 && M != 6 && M != 8) M = 0;
     if (M == 4 && ((long long)bands * groups_x) % 8 != 0) M = 0;
     if (S && (unsigned)bands % strides[S] == 0) S = 0;
     if (bands < 2) A = 0;          // A = 1: alternating heights; A = 2..9: start stagger probe (see stagger_start)
