@@ -57,14 +57,19 @@ struct TapsF { float k[9]; float inv, half_inv; };
 
 template <int R, int C>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                                      int wb, int h, int groups_x, TapsF t)
+                                                                      int wb, int h, int groups_x, int order, TapsF t)
 {
     using namespace stream_core;
     constexpr int NROWS = R + 2;
     static_assert(NROWS % C == 0, "R + 2 must be a multiple of the chunk");
     constexpr int NCH = NROWS / C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
+    BandPlan plan{};                       // only the workgroup -> (band, column) mapping is used (see stream_core::band_of_block)
+    plan.bands = (h + R - 1) / R;
+    plan.order = order;
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    if (gy_i < 0) return;
     const int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;   // first BYTE of this wave's strip
     if (xw >= wb) return;
     const int x = xw + 16 * lane;
@@ -186,11 +191,14 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
             const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
             R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
         }
-        const long long nb = (long long)groups_x * ((height + R - 1) / R);
+        stream_core::BandPlan plan{};
+        plan.bands = (height + R - 1) / R;
+        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x);   // band-per-XCD, as the fused kernel
+        const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
-        else if (R == 32) k_conv3x3_stream<32, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
-        else k_conv3x3_stream<16, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, t);
+        if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
+        else if (R == 32) k_conv3x3_stream<32, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
+        else k_conv3x3_stream<16, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
     } else {
         Taps t;
         for (int i = 0; i < 9; ++i) t.k[i] = kernel[i];
