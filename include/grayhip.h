@@ -76,6 +76,10 @@ GH_API int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t n
 /* Reference ABI semantics on device memory: R=G=B=luma in place, alpha untouched.
  * channels<3 is a no-op (the reference reads out of bounds there). */
 GH_API int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mode, gh_stream_t stream);
+/* `passes` applications of convert_to_grayscale in ONE launch (the driver loop of monolithic/src/main.c:33-35): passes
+ * 2..N see a grey pixel (y, y, y) and map it to lum(y, y, y); they are independent per pixel, so they run in registers
+ * between one load and one store -- the same arithmetic as N launches, bit-identical result. */
+GH_API int gh_gray_inplace_passes_dev(uint8_t *data, size_t npix, int channels, int mode, int passes, gh_stream_t stream);
 
 /* 3x3 Sobel magnitude, u8 plane -> u8 plane, whole frame; border pixels are written as 0.
  * width<3 or height<3: dst is all zeros. */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "gh_stream_sync": (C.c_int, [_stream]),
     "gh_gray_rgb8_to_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
     "gh_gray_inplace_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
+    "gh_gray_inplace_passes_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sobel_u8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sobel_u8_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_gray_sobel_fused_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),

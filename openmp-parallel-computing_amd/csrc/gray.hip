@@ -36,6 +36,16 @@ __device__ __forceinline__ void luma16_rgb(const uint32_t (&w)[12], uint32_t (&l
     }
 }
 
+// passes 2..N of the reference's driver loop (monolithic/src/main.c:33-35) see a grey pixel (y, y, y): pass k+1 maps it to
+// lum(y, y, y), which is NOT the identity for every y in IEEE mode.  The passes are independent per pixel, so a launch
+// can run all of them in registers (same arithmetic as N launches, no memory round trips in between).
+template <int MODE>
+__device__ __forceinline__ uint32_t luma_again(uint32_t y, int extra)
+{
+    for (int p = 0; p < extra; ++p) y = gh_luma<MODE>(y, y, y);
+    return y;
+}
+
 __device__ __forceinline__ uint4 pack16(const uint32_t (&v)[16])
 {
     uint4 o;
@@ -79,7 +89,7 @@ __device__ __forceinline__ void replicate48(const uint32_t (&v)[16], uint32_t (&
 
 // in place: same read path; the 48 replicated output bytes go back through the slab so the stores are coalesced too
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb_w(uint4 *__restrict__ data, size_t nwavegroups)
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb_w(uint4 *__restrict__ data, size_t nwavegroups, int extra)
 {
     __shared__ __attribute__((aligned(16))) uint8_t slab[BLOCK / 64][3072];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,6 +98,10 @@ __global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb_w(uint4 *__restrict_
         uint32_t w[12], lum[16], o[12];
         stream_core::wave_load_rgb48(slab[wave], data + g * 192, lane, w);
         luma16_rgb<MODE>(w, lum);
+        if (extra) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lum[k] = luma_again<MODE>(lum[k], extra);
+        }
         replicate48(lum, o);
         stream_core::wave_store_rgb48(slab[wave], data + g * 192, lane, o);
     }
@@ -159,13 +173,17 @@ __global__ __launch_bounds__(BLOCK) void k_gray_rgba_to_plane(const uint4 *__res
 
 // ---- in place, reference ABI: R=G=B=luma, alpha untouched --------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb(uint4 *__restrict__ data, size_t ngroups)
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb(uint4 *__restrict__ data, size_t ngroups, int extra)
 {
     const size_t stride = (size_t)gridDim.x * BLOCK;
     for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
         uint32_t w[12], lum[16], o[12];
         load48(data + 3 * g, w);
         luma16_rgb<MODE>(w, lum);
+        if (extra) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lum[k] = luma_again<MODE>(lum[k], extra);
+        }
 #pragma unroll
         for (int j = 0; j < 12; ++j) {   // output byte k of the 48 is lum[k / 3]
             o[j] = lum[(4 * j) / 3] | (lum[(4 * j + 1) / 3] << 8) | (lum[(4 * j + 2) / 3] << 16) |
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb(uint4 *__restrict__ 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgba(uint4 *__restrict__ data, size_t nquads)
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgba(uint4 *__restrict__ data, size_t nquads, int extra)
 {
     // one uint4 = 4 RGBA pixels
     const size_t stride = (size_t)gridDim.x * BLOCK;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgba(uint4 *__restrict__
         uint32_t px[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t y = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
+            const uint32_t y = luma_again<MODE>(gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2)), extra);
             px[k] = (px[k] & 0xff000000u) | (y * 0x00010101u);
         }
         data[q] = make_uint4(px[0], px[1], px[2], px[3]);
@@ -208,12 +226,12 @@ __global__ __launch_bounds__(BLOCK) void k_gray_to_plane_px(const uint8_t *__res
 
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_gray_inplace_px(uint8_t *__restrict__ data, size_t first, size_t npix,
-                                                           int channels)
+                                                           int channels, int extra)
 {
     const size_t stride = (size_t)gridDim.x * BLOCK;
     for (size_t i = first + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < npix; i += stride) {
         uint8_t *p = data + i * channels;
-        const uint8_t y = (uint8_t)gh_luma<MODE>(p[0], p[1], p[2]);
+        const uint8_t y = (uint8_t)luma_again<MODE>(gh_luma<MODE>(p[0], p[1], p[2]), extra);
         p[0] = y; p[1] = y; p[2] = y;
     }
 }
@@ -361,7 +379,14 @@ int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, in
 
 int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mode, gh_stream_t stream)
 {
+    return gh_gray_inplace_passes_dev(data, npix, channels, mode, 1, stream);
+}
+
+int gh_gray_inplace_passes_dev(uint8_t *data, size_t npix, int channels, int mode, int passes, gh_stream_t stream)
+{
     GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    GH_REQUIRE(passes >= 1, "passes must be >= 1");
+    const int extra = passes - 1;
     GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
     if (npix == 0 || channels < 3) return GH_OK;   // channels 1/2: undefined in the reference, no-op here
     GH_REQUIRE(data, "null pointer");
@@ -375,29 +400,29 @@ int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mode, gh_s
             const size_t nwg = ngroups / 64;
             if (nwg) {
                 const unsigned gw = grid_for(nwg * 64);
-                if (mode == GH_MODE_FMA) k_gray_inplace_rgb_w<GH_MODE_FMA><<<gw, BLOCK, 0, s>>>(p, nwg);
-                else k_gray_inplace_rgb_w<GH_MODE_IEEE><<<gw, BLOCK, 0, s>>>(p, nwg);
+                if (mode == GH_MODE_FMA) k_gray_inplace_rgb_w<GH_MODE_FMA><<<gw, BLOCK, 0, s>>>(p, nwg, extra);
+                else k_gray_inplace_rgb_w<GH_MODE_IEEE><<<gw, BLOCK, 0, s>>>(p, nwg, extra);
                 GH_LAUNCH_CHECK();
             }
             const size_t rest = ngroups - nwg * 64;
             if (rest) {
-                if (mode == GH_MODE_FMA) k_gray_inplace_rgb<GH_MODE_FMA><<<1, BLOCK, 0, s>>>(p + nwg * 192, rest);
-                else k_gray_inplace_rgb<GH_MODE_IEEE><<<1, BLOCK, 0, s>>>(p + nwg * 192, rest);
+                if (mode == GH_MODE_FMA) k_gray_inplace_rgb<GH_MODE_FMA><<<1, BLOCK, 0, s>>>(p + nwg * 192, rest, extra);
+                else k_gray_inplace_rgb<GH_MODE_IEEE><<<1, BLOCK, 0, s>>>(p + nwg * 192, rest, extra);
             }
             done = ngroups * PX_PER_LANE;
         } else {
             const size_t nquads = npix / 4;
             const unsigned grid = grid_for(nquads);
-            if (mode == GH_MODE_FMA) k_gray_inplace_rgba<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(p, nquads);
-            else k_gray_inplace_rgba<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(p, nquads);
+            if (mode == GH_MODE_FMA) k_gray_inplace_rgba<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(p, nquads, extra);
+            else k_gray_inplace_rgba<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(p, nquads, extra);
             done = nquads * 4;
         }
         GH_LAUNCH_CHECK();
     }
     if (done < npix) {
         const unsigned grid = grid_for(npix - done);
-        if (mode == GH_MODE_FMA) k_gray_inplace_px<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(data, done, npix, channels);
-        else k_gray_inplace_px<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(data, done, npix, channels);
+        if (mode == GH_MODE_FMA) k_gray_inplace_px<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(data, done, npix, channels, extra);
+        else k_gray_inplace_px<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(data, done, npix, channels, extra);
         GH_LAUNCH_CHECK();
     }
     return GH_OK;

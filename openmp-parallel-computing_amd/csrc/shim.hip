@@ -39,6 +39,7 @@ struct Scratch {
 Scratch g_img, g_gray, g_edge;
 std::mutex g_host_mu;
 
+
 int do_init(int device)
 {
     int n = 0;
@@ -241,8 +242,8 @@ int gh_gray_passes_host(unsigned char *data, int width, int height, int channels
     GH_HIP_TRY(hipMemcpy(g_img.p, data, nbytes, hipMemcpyHostToDevice));
     EventTimer t;
     if (int rc = t.start(nullptr)) return rc;
-    for (int p = 0; p < passes; ++p)
-        if (int rc = gh_gray_inplace_dev((uint8_t *)g_img.p, npix, channels, mode, nullptr)) return rc;
+    // all passes in one launch: they are independent per pixel (gh_gray_inplace_passes_dev)
+    if (int rc = gh_gray_inplace_passes_dev((uint8_t *)g_img.p, npix, channels, mode, passes, nullptr)) return rc;
     if (int rc = t.stop(nullptr, kernel_seconds)) return rc;
     GH_HIP_TRY(hipMemcpy(data, g_img.p, nbytes, hipMemcpyDeviceToHost));
     return GH_OK;
@@ -285,6 +286,8 @@ int gh_pipeline_gray_sobel_host(unsigned char *img, int width, int height, int c
     if (int rc = g_gray.reserve(npix)) return rc;
     if (int rc = g_edge.reserve(npix)) return rc;
     GH_HIP_TRY(hipMemcpy(g_img.p, img, nbytes, hipMemcpyHostToDevice));
+    // (Replaying passes 2..N as a hipGraph was tried: 15.3 ms vs 15.2 ms for 1000 passes on a 1080p frame -- the cost is
+    //  the ~7 us dispatch of each dependent kernel on the GPU side, not the host-side launches, so plain launches stay.)
     EventTimer t;
     if (int rc = t.start(nullptr)) return rc;
     if (int rc = gh_pipeline_gray_sobel_dev((uint8_t *)g_img.p, width, height, channels, passes, mode, (uint8_t *)g_gray.p,

@@ -147,9 +147,11 @@ def gray_to_plane(rgb, mode: int = MODE_IEEE, out=None):
     return out
 
 
-def gray_inplace(img, mode: int = MODE_IEEE):
+def gray_inplace(img, mode: int = MODE_IEEE, passes: int = 1):
+    """In-place convert_to_grayscale on a device (h, w, c) frame; passes > 1 = the reference driver's pass loop
+    (main.c:33-35) fused into one launch."""
     h, w, c = img.shape
-    check(abi.load().gh_gray_inplace_dev(_dev_ptr(img), h * w, c, mode, _stream()), "gray_inplace")
+    check(abi.load().gh_gray_inplace_passes_dev(_dev_ptr(img), h * w, c, mode, passes, _stream()), "gray_inplace")
     return img
 
 

@@ -627,3 +627,25 @@ def test_device_entry_points_are_graph_capturable(pkg, oracle, torch_mod):
         g.replay()
         t.cuda.synchronize()
         assert np.array_equal(e1.cpu().numpy(), want) and np.array_equal(e2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,c", [(200, 121, 3), (333, 77, 4), (1024, 64, 3), (17, 5, 3)])
+def test_many_passes(pkg, oracle, torch_mod, w, h, c):
+    """The reference's bench script runs its gray driver with hundreds of passes (bench_and_plot_monolithic.sh): here all of
+    them run in ONE launch (per-pixel independent, gh_gray_inplace_passes_dev).  Gray and gray+Sobel drivers must equal N
+    sequential passes of the oracle, bit for bit."""
+    img = oracle.frame_rand(w, h, c, seed=w + h + c)
+    for mode in (0, 1):
+        for passes in (1, 2, 5, 40, 1000):
+            want = oracle.gray_passes(img, passes, mode)
+            host = img.copy()
+            pkg.hostapi.gray_passes(host, w, h, c, passes, mode)
+            assert np.array_equal(host, want), ("gray host", passes, mode)
+            d = dev(torch_mod, img)
+            pkg.hostapi.gray_inplace(d, mode, passes=passes)
+            assert np.array_equal(d.cpu().numpy(), want), ("gray dev", passes, mode)
+    for passes in (7, 8, 9, 70, 131):
+        want_img, _, _ = oracle.pipeline(img, passes, 0)
+        host = img.copy()
+        pkg.hostapi.pipeline_gray_sobel(host, w, h, c, passes, 0)
+        assert np.array_equal(host, want_img), ("pipeline", passes)
