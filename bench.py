@@ -202,6 +202,7 @@ def main() -> int:
 
     # N > 1: who issues the halo exchange.  native = libgrayhip's own RCCL communicator, whole step in one C++ call.
     native, exchange, exchange_note = None, "none", ""
+    comms_to_close = []
     if world > 1:
         exchange = "torch.distributed P2P (batch_isend_irecv over RCCL)"
         if args.exchange == "native":
@@ -213,6 +214,8 @@ def main() -> int:
                     native = sharding.NativeHaloComm(rank, world)
             except Exception as exc:
                 exchange_note = f"native communicator unavailable on rank {rank}: {exc}"
+            if native is not None:
+                comms_to_close.append(native)
             if not all_ranks_agree(native is not None):
                 native = None
 
@@ -470,7 +473,13 @@ def main() -> int:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if world > 1:
+        torch.cuda.synchronize()
         dist.barrier()
+        for comm in comms_to_close:        # every rank has finished with the communicator: release it before the process group
+            try:
+                comm.close()
+            except Exception:
+                pass
         dist.destroy_process_group()
     return 0
 
