@@ -1,7 +1,7 @@
 // main_gray.cpp -- drop-in for the reference's grayscale CLI (monolithic/src/main.c:14-49):
 //   grayscale <input_img> <output_img.png> [passes]
 // Same argv, same stdout line, same exit codes and stderr texts; the kernel passes run on MI355X
-// through libgrayhip's C ABI (one upload, `passes` launches, one download).  stderr stays empty on
+// through libgrayhip's C ABI (one upload, all passes in one launch, one download).  stderr stays empty on
 // success: the reference's bench script parses the child's stderr together with /usr/bin/time's line.
 // With GRAYHIP_SERVER=<socket> and a bin/grayhipd listening there, the request is served by that warm
 // process instead (no HIP start-up per call); without one, everything happens here.
