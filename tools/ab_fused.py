@@ -23,10 +23,15 @@ plane = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda")
 out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda") if a.op == "fused4" else None
 out3 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") if a.op in ("conv", "minmax") else None
+scr = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda") if a.op in ("inplace", "replicate") else None
 mm = torch.tensor([256, -1], dtype=torch.int32, device="cuda")
 sums = torch.zeros(3, dtype=torch.int64, device="cuda")
 ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (lambda: api.sobel(plane, out=out), 2),
        "gray": (lambda: api.gray_to_plane(rgb, 0, out=out), 4),
+       "inplace": (lambda: api.gray_inplace(scr, 0), 6),
+       "extract": (lambda: api.extract_plane(rgb, out=out), 4),
+       "replicate": (lambda: api.replicate_plane(plane, scr), 4),
+       "grayplane": (lambda: api.gray_of_plane(plane, 0, out=out), 2),
        "fused4": (lambda: api.gray_sobel_fused(rgba, 0, out=out), 5),
        "conv": (lambda: api.conv3x3(rgb, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16, out=out3), 6),
        "minmax": (lambda: pkg.abi.check(pkg.abi.load().gh_mean_gray_minmax_dev(rgb.data_ptr(), out3.data_ptr(), W * H, mm.data_ptr(), torch.cuda.current_stream().cuda_stream)), 6),
