@@ -325,8 +325,10 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
         if (use_dma) {
+            // dispatch order 8 (pairs-per-XCD: XCD x owns the band pairs p = x mod 8): +1-2 % on 16384^2 in four interleaved
+            // A/B runs, +14 % on 32768 x 8192, neutral on shards (tools/ab_fused.py --op sobel)
             stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 0), plan.bands, groups_x);
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), plan.bands, groups_x);
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
             
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
