@@ -256,7 +256,6 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     // band plan: n[0] bands of R[0] rows, then n[1] of R[1], then bands of R[2] (shorter bands last: a short drain)
     if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    stagger_start(plan, gy_i);
     if (plan.order / 1000 == 1) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
         y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
         R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
@@ -269,6 +268,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     }
     const int nrows = min(R, rows - y0) + 2;                     // input rows of this band (clipped to the frame) incl. halo
     const int nch = (nrows + CHK - 1) / CHK;
+    const bool up = band_walks_up(plan, gy_i);
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw * CH + (uint32_t)lane * 16u;            // byte offset of this lane's piece in a row
     // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its bytes 1..3),
@@ -281,7 +281,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     st.clear();
 
     auto issue_row = [&](int i, int slot) {
-        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * CH);
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         if (CH == 3) glds_row3k<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, rowb, voff); else glds_row4k(dst, rowb, voff);
@@ -318,7 +318,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
                 if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
                 else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
                 if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
-                    const int y = y0 + i - 2;
+                    const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
                     if (x == 0) out.x &= 0xffffff00u;
                     if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                     if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);

@@ -128,7 +128,6 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     const int x = xw + 16 * lane;
     if (gy_i < 0) return;
     int R = plan.R[0], y0 = gy_i * plan.R[0];
-    stagger_start(plan, gy_i);
     if (plan.order / 1000 == 1) {            // alternating heights R-1, R+1: band starts alternate between even and odd rows
         y0 = (gy_i >> 1) * 2 * plan.R[0] + ((gy_i & 1) ? plan.R[0] - 1 : 0);
         R = (gy_i & 1) ? plan.R[0] + 1 : plan.R[0] - 1;
@@ -141,6 +140,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     }
     const int nrows = min(R, rows - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
+    const bool up = band_walks_up(plan, gy_i);
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     st.clear();
 
     auto issue_row = [&](int i, int slot) {
-        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         glds_row1k(d, rowb, voff);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
                 G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
                 uint4 out = (j & 1) ? rowf2<1, 1, PROBE>(st, G, half2) : rowf2<0, 1, PROBE>(st, G, half2);
                 if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
-                    const int y = y0 + i - 2;
+                    const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
                     if (x == 0) out.x &= 0xffffff00u;
                     if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                     if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);

@@ -399,7 +399,8 @@ inline BandPlan make_band_plan(int rows, int R0, int n0, int R1, int n1, int R2)
 //                 pairs of neighbouring bands
 //   C (tens)      column group rotated by C * band
 //   S (hundreds)  bands visited with stride {1, 37, 3, 5, 7, 11, 13, 17, 19, 23}[S] (a permutation when co-prime to the count)
-//   A (thousands) 1: band heights alternate R-1, R+1 (band starts alternate between even and odd rows)
+//   A (thousands) 1: band heights alternate R-1, R+1 (band starts alternate between even and odd rows); 2: odd bands walk
+//                 upward (band_walks_up)
 // Which mapping is fastest is decided by how the rows that are in flight at the same time spread over the memory
 // channels; measured on MI355X: see DESIGN.md.
 __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk, int groups_x, int &gx, int &gy)
@@ -430,15 +431,10 @@ __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk
     }
 }
 
-// Start stagger probe (order thousands digit A = 2..9): band gy waits (gy * 5 % 8) * 2^(A-2) * ~0.13 us before its first
-// load, so that the bands do not walk their rows in lockstep.
-__device__ __forceinline__ void stagger_start(const BandPlan &plan, int gy)
-{
-    const int A = (plan.order / 1000) % 10;
-    if (A < 2) return;
-    const int n = ((gy * 5) & 7) << (A - 2);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);       // 4 * 64 cycles ~ 0.13 us
-}
+// Walk direction of a band (order thousands digit A = 2): odd bands walk UPWARD, so that the two bands of a pair meet at
+// their common boundary at the end of their lives and the shared halo rows are read by both at about the same time.
+// The rolling Sobel window is symmetric under the reversal (gy changes sign, and is squared).
+__device__ __forceinline__ bool band_walks_up(const BandPlan &plan, int gy) { return (plan.order / 1000) % 10 == 2 && (gy & 1); }
 
 // host side: workgroups to launch for a plan (the band-per-XCD order pads the band count to a multiple of 8: surplus
 // workgroups find gy < 0 and exit)
@@ -458,7 +454,7 @@ inline int sanitize_order(int order, int bands, int groups_x)
     if (M != 0 && M != 2 && M != 4 && M != 6 && M != 8) M = 0;
     if (M == 4 && ((long long)bands * groups_x) % 8 != 0) M = 0;
     if (S && (unsigned)bands % strides[S] == 0) S = 0;
-    if (bands < 2) A = 0;          // A = 1: alternating heights; A = 2..9: start stagger probe (see stagger_start)
+    if (bands < 2 || A > 2) A = 0;          // A = 1: alternating heights; A = 2: odd bands walk upward
     return A * 1000 + S * 100 + C * 10 + M;
 }
 

@@ -213,7 +213,7 @@ def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
                                     "GH_FUSED_DMA_R2": "16"}, {"GH_FUSED_DMA": "0", "GH_FUSED_VARIANT": "1"},
                                    {"GH_FUSED_DMA_R": "24", "GH_FUSED_DMA_ORDER": "2"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "1234"},
                                    {"GH_FUSED_DMA_R": "40", "GH_FUSED_DMA_ORDER": "1010"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "304"},
-                                   {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "0"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "36"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "8"}])
+                                   {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "0"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "36"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "8"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "2008"}, {"GH_FUSED_DMA_ORDER": "2006"}])
 def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     """Every tuning variant of the fused kernel (register-staged, LDS-DMA ring depths, band plans) is bit-exact too.
     tests/conftest.py sets GH_TUNE_DYNAMIC so that the library re-reads the knobs on every launch."""
@@ -231,7 +231,7 @@ def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
                                    {"GH_SOBEL_DMA": "8"}, {"GH_SOBEL_DMA": "6", "GH_SOBEL_R": "16"}, {"GH_SOBEL_DMA": "0", "GH_SOBEL_R": "32"},
                                    {"GH_SOBEL_R": "24", "GH_SOBEL_ORDER": "2"}, {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "1234"},
                                    {"GH_SOBEL_R": "40", "GH_SOBEL_ORDER": "1010"}, {"GH_SOBEL_R": "128", "GH_SOBEL_ORDER": "4"},
-                                   {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "6"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "36"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "8"}])
+                                   {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "6"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "36"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "8"}, {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "2008"}, {"GH_SOBEL_ORDER": "2000"}])
 def test_sobel_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     """Register-staged and LDS-DMA forms of the plane Sobel kernel, every ring depth: bit-exact, including bands
     (halo rows above / below) and the shifted last strip of widths that are not a multiple of 1024."""
