@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel measurements after the timed region")
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity spot check against the oracle")
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed run-in before the W warm-up steps: after ~2 ms of load the GPU's power management dips the clocks and "
+                         "takes 30-60 ms to settle (tools/drift_start.py: launches 10-40 of a burst run 25-40 %% slower); "
+                         "the timed K steps are meant to see the settled chip")
     return ap.parse_args()
 
 
@@ -311,6 +315,12 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.settle_ms > 0:           # run-in (untimed, before the warm-up steps): let the clocks settle under this very load
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(16):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -460,6 +470,7 @@ def main() -> int:
             "parity_spot_check": check,
             "halo_rows_check": "ok" if halo_ok else "MISMATCH",
             "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1),
+            "settle_ms": args.settle_ms,
         }
         if rehearsal:
             out["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
