@@ -390,7 +390,7 @@ def main() -> int:
 
     # per-kernel table (outside the timed region): every kernel of the hot path on this rank's shard
     def time_kernel(fn, reps=30):
-        for _ in range(3):
+        for _ in range(150):      # run-in: a change of kernel is followed by the same clock dip as a start from idle
             fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)

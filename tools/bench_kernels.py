@@ -10,7 +10,7 @@ rgb = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda")
 rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda")
 plane = torch.empty((H, W), dtype=torch.uint8, device="cuda"); plane2 = torch.empty_like(plane); out3 = torch.empty_like(rgb)
 def t(fn, reps=20):
-    for _ in range(3): fn()
+    for _ in range(120): fn()      # run-in: a change of kernel is followed by a clock dip (tools/drift_start.py)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); [fn() for _ in range(reps)]; b.record(); b.synchronize(); return a.elapsed_time(b) / reps
 rows = []
