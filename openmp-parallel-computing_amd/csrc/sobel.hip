@@ -24,8 +24,11 @@ using namespace sobel_tile;
 // MODE.fp_round = toward zero: this kernel has no rounding-sensitive float op (all sums are exact integers).
 template <int R, int C, int CORE>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
-                                                                    int rows, int groups_x, int zero_top, int zero_bot)
+                                                                    int rows, int groups_x, int zero_top, int zero_bot, int ws)
 {
+    // w: frame width = row pitch (rows need not be 16-byte aligned: the vector accesses below are then unaligned, which
+    // gfx950 global memory instructions handle); ws <= w, a multiple of 16: the columns covered by strips.  Columns
+    // [ws, w) of a frame whose width is not a multiple of 16 are left to k_sobel_px_cols.
     using namespace stream_core;
     static_assert(C % 2 == 0, "chunk must be even: the h2 ring slot is the row parity");
     constexpr int NROWS = R + 2;
@@ -33,15 +36,16 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
     constexpr int NCH = NROWS / C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
-    const int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;   // first pixel of this wave's strip
-    if (xw >= w) return;
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;         // first pixel of this wave's strip
+    if (xw >= ws) return;
+    if (xw + STRIP_PX > ws && ws >= STRIP_PX) xw = ws - STRIP_PX;   // last strip shifted left onto its neighbour: every strip is full
     const int x = xw + 16 * lane;
     const int y0 = gy_i * R;
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const float half = half_reg();
     const f32x2 half2 = {half, half};
-    const bool in_frame = x < w;
-    const bool full = xw + STRIP_PX <= w;                        // wave-uniform: no lane predication needed
+    const bool in_frame = x < ws;
+    const bool full = xw + STRIP_PX <= ws;                       // wave-uniform: no lane predication needed
     const int hx = lane == 0 ? xw - 1 : xw + STRIP_PX;           // pixel just outside the strip, fetched by lanes 0 / 63
     const bool hvalid = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
 
@@ -56,7 +60,11 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
             const int yy = clamp_row(y0 - 1 + ch * C + j, rows, zero_top, zero_bot);   // always a readable row
             const uint8_t *rowp = src + (ptrdiff_t)yy * w;
             if (full) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
-            else { q[j] = make_uint4(0, 0, 0, 0); if (in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x)); }
+            else {
+                q[j] = make_uint4(0, 0, 0, 0);
+                if (in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
+                else if (x == ws && ws < w) q[j].x = rowp[ws];     // column ws exists (w % 16 != 0): right neighbour of the last strip column
+            }
             hb[j] = 0;
             if (hvalid) hb[j] = rowp[hx];
         }
@@ -259,6 +267,28 @@ __global__ __launch_bounds__(BLOCK) void k_sobel_px(const uint8_t *__restrict__ 
     }
 }
 
+// The last w % 16 columns of a frame whose width is not a multiple of 16 (the strip kernel covers the rest).
+__global__ __launch_bounds__(BLOCK) void k_sobel_px_cols(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int x0,
+                                                         int zero_top, int zero_bot)
+{
+    const int nc = w - x0;
+    const size_t n = (size_t)nc * rows;
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / nc), x = x0 + (int)(i - (size_t)y * nc);
+        uint32_t out = 0;
+        const bool border = x == 0 || x == w - 1 || (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
+        if (!border) {
+            const uint8_t *m = src + (ptrdiff_t)y * w + x;
+            const uint8_t *u = m - w, *d = m + w;
+            const int gx = -(int)u[-1] - 2 * (int)m[-1] - (int)d[-1] + (int)u[1] + 2 * (int)m[1] + (int)d[1];
+            const int gy = (int)u[-1] + 2 * (int)u[0] + (int)u[1] - (int)d[-1] - 2 * (int)d[0] - (int)d[1];
+            out = gh_sobel_mag(gx * gx + gy * gy);
+        }
+        dst[(size_t)y * w + x] = (uint8_t)out;
+    }
+}
+
 // every reachable gradient pair (gx, gy) in [-1020, 1020]^2 through the magnitude mapping of one core
 //   variant 0: stream_core::mag_pack_rtz (packed-i16 core, MODE = RTZ)   variant 1: stream_core::mag_pack_rne (f32 core)
 //   variant 2: gh_sobel_mag on m = gx^2 + gy^2 (LDS-tile and per-pixel kernels)
@@ -303,17 +333,25 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     hipStream_t s = (hipStream_t)stream;
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
     static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
-    if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst) && !use_tile) {
+    const bool aligned = width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst);
+    // Widths that are not a multiple of 16 (or unaligned planes): the register-staged strip kernel runs on the first
+    // ws = width & ~15 columns with unaligned vector accesses (rows start at arbitrary bytes), the per-pixel kernel takes
+    // the last width % 16 columns.  (All per-pixel: 0.69 ms on 16370 x 16384; this way: 0.125 ms.)
+    const int ws = width & ~15;
+    // (small unaligned frames stay on the single per-pixel launch: 1921 x 1081 takes 7 us that way, 11 us as strips + tail)
+    const bool strips = !use_tile && ws >= 16 &&
+                        (aligned || (GH_TUNE_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_TUNE_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
+    if (strips) {
         static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
         const int r_env = GH_TUNE_INT("GH_SOBEL_R", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = (width + span - 1) / span;
+        const int groups_x = (ws + span - 1) / span;
         // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 64)
         // but a shard must still give every CU a few workgroups.  Power-of-two heights only: band starts aligned to
         // 2^k rows measured 10-15 % faster than 30 / 34 / 48 / 60-row bands in the no-compute strip-copy probe.
         int R = r_env;
         const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
-        const bool use_dma = dma && core == 1 && width >= stream_core::STRIP_PX;
+        const bool use_dma = dma && core == 1 && aligned && width >= stream_core::STRIP_PX;
         // the LDS-DMA kernel takes any band height (tuning knob); the register-staged one is instantiated for 16 / 32 / 64
         if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
@@ -346,8 +384,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         }
 #define GH_SOBEL_LAUNCH(R_, C_)                                                                                      \
         do {                                                                                                         \
-            if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);       \
-            else k_sobel_stream<R_, C_, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb);                 \
+            if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);       \
+            else k_sobel_stream<R_, C_, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                 \
         } while (0)
         switch (R) {
         case 64: GH_SOBEL_LAUNCH(64, 2); break;
@@ -355,7 +393,13 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         default: GH_SOBEL_LAUNCH(16, 2); break;
         }
 #undef GH_SOBEL_LAUNCH
-    } else if (width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst)) {
+        if (ws < width) {
+            GH_LAUNCH_CHECK();
+            size_t blocks = ((size_t)(width - ws) * rows + BLOCK - 1) / BLOCK;
+            if (blocks > 4096) blocks = 4096;
+            k_sobel_px_cols<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, rows, ws, zt, zb);
+        }
+    } else if (aligned) {
         const int tiles_x = (width + TW - 1) / TW;
         const int tiles_y = (rows + TH - 1) / TH;
         const long long nt = (long long)tiles_x * tiles_y;

@@ -649,3 +649,19 @@ def test_many_passes(pkg, oracle, torch_mod, w, h, c):
         host = img.copy()
         pkg.hostapi.pipeline_gray_sobel(host, w, h, c, passes, 0)
         assert np.array_equal(host, want_img), ("pipeline", passes)
+
+
+@pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2)])
+def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, monkeypatch):
+    """Frame widths that are not a multiple of 16 (rows start at unaligned bytes): the strip kernel covers the first
+    w & ~15 columns with unaligned vector accesses, a per-pixel kernel the rest; forced on for small frames here."""
+    monkeypatch.setenv("GH_SOBEL_UNALIGNED_MIN_PX", "1")
+    plane = oracle.frame_rand(w, h, 1, seed=w + h).reshape(h, w)
+    want = oracle.sobel(plane)
+    assert np.array_equal(pkg.hostapi.sobel(dev(torch_mod, plane)).cpu().numpy(), want)
+    if h >= 3:    # middle band with real halo rows
+        got = torch_mod.empty((h - 2, w), dtype=torch_mod.uint8, device="cuda")
+        pkg.hostapi.sobel_rows(dev(torch_mod, plane), got, h - 2, False, False)
+        assert np.array_equal(got.cpu().numpy(), want[1:h - 1])
+    monkeypatch.setenv("GH_SOBEL_UNALIGNED", "0")          # and the all-per-pixel path still agrees
+    assert np.array_equal(pkg.hostapi.sobel(dev(torch_mod, plane)).cpu().numpy(), want)
