@@ -5,9 +5,11 @@
 //   k_sobel_dma    : default fast path (width % 16 == 0, width >= 1024, 16-byte aligned planes): strip streaming -- 3x3
 //                    reuse in registers, halo through DPP (stream_core.h) -- with rows brought HBM -> LDS by LDS-DMA
 //                    (global_load_lds_dwordx4), three rows deep; GH_SOBEL_DMA=0 turns it off
-//   k_sobel_stream : the same strip streaming with register-staged loads (narrow frames, GH_SOBEL_DMA=0)
+//   k_sobel_stream : the same strip streaming with register-staged loads: narrow frames, GH_SOBEL_DMA=0, and -- with
+//                    unaligned vector accesses -- frames whose width is not a multiple of 16 or whose planes are not
+//                    16-byte aligned (first width & ~15 columns; k_sobel_px_cols takes the remaining columns)
 //   k_sobel_tiled  : the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h); GH_SOBEL_IMPL=tile
-//   k_sobel_px     : one pixel per lane, any geometry / alignment (odd widths, unaligned planes)
+//   k_sobel_px     : one pixel per lane, any geometry / alignment (small unaligned frames, widths < 16)
 #include "sobel_tile.h"
 #include "stream_core.h"
 
