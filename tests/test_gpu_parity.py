@@ -663,5 +663,16 @@ def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h,
         got = torch_mod.empty((h - 2, w), dtype=torch_mod.uint8, device="cuda")
         pkg.hostapi.sobel_rows(dev(torch_mod, plane), got, h - 2, False, False)
         assert np.array_equal(got.cpu().numpy(), want[1:h - 1])
+    # width a multiple of 16 but planes that start at odd bytes
+    w2 = (w + 15) & ~15
+    plane2 = oracle.frame_rand(w2, h, 1, seed=w2 + h).reshape(h, w2)
+    raw_in = torch_mod.zeros(h * w2 + 32, dtype=torch_mod.uint8, device="cuda")
+    raw_out = torch_mod.zeros(h * w2 + 32, dtype=torch_mod.uint8, device="cuda")
+    src = raw_in[5:5 + h * w2].view(h, w2)
+    dst = raw_out[9:9 + h * w2].view(h, w2)
+    src.copy_(dev(torch_mod, plane2))
+    pkg.hostapi.sobel(src, out=dst)
+    assert np.array_equal(dst.cpu().numpy(), oracle.sobel(plane2))
+    assert not raw_out[:9].any() and not raw_out[9 + h * w2:].any()          # nothing written outside the plane
     monkeypatch.setenv("GH_SOBEL_UNALIGNED", "0")          # and the all-per-pixel path still agrees
     assert np.array_equal(pkg.hostapi.sobel(dev(torch_mod, plane)).cpu().numpy(), want)
