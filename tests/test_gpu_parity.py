@@ -554,6 +554,14 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
         native_comm.set_loopback(False)
 
 
+def test_streamed_frame_with_a_width_that_is_not_a_multiple_of_16(pkg, oracle):
+    w, h = 1037, 150
+    img = oracle.frame_rand(w, h, 3, seed=5)
+    got = np.zeros((h, w), dtype=np.uint8)
+    pkg.hostapi.gray_sobel_streamed(img, got, tile_rows=41)
+    assert np.array_equal(got, oracle.sobel(oracle.gray_to_plane(img, 0)))
+
+
 def test_streamed_row_blocks_equal_whole_frame(pkg, oracle):
     """A host frame split into row blocks (one per GPU in the 8-GPU streamed configuration): each block streamed on its own,
     halo rows read from host memory next to it, equals the whole-frame result."""
