@@ -196,6 +196,15 @@ def gray_sobel_fused_rows(buf, out, rows: int, mode: int, top_is_border: bool, b
     return out
 
 
+def gray_sobel(rgb, mode: int = MODE_IEEE, out=None):
+    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane for ANY width: the fused kernel when the width is a multiple of 16 and the
+    buffers are 16-byte aligned, otherwise gray -> plane Sobel (two kernels, a temporary luma plane)."""
+    h, w, c = rgb.shape
+    if w % 16 == 0 and rgb.data_ptr() % 16 == 0 and (out is None or out.data_ptr() % 16 == 0):
+        return gray_sobel_fused(rgb, mode, out=out)
+    return sobel(gray_to_plane(rgb, mode), out=out)
+
+
 def extract_plane(img, out=None):
     import torch
     h, w, c = img.shape

@@ -554,6 +554,12 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
         native_comm.set_loopback(False)
 
 
+def test_gray_sobel_any_width(pkg, oracle, torch_mod):
+    for (w, h, c) in ((1037, 40, 3), (1040, 40, 4), (19, 7, 3)):
+        img = oracle.frame_rand(w, h, c, seed=w)
+        assert np.array_equal(pkg.hostapi.gray_sobel(dev(torch_mod, img), 1).cpu().numpy(), oracle.sobel(oracle.gray_to_plane(img, 1)))
+
+
 def test_streamed_frame_with_a_width_that_is_not_a_multiple_of_16(pkg, oracle):
     w, h = 1037, 150
     img = oracle.frame_rand(w, h, 3, seed=5)
