@@ -92,7 +92,8 @@ GH_API int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int
                                 int top_is_border, int bottom_is_border, gh_stream_t stream);
 
 /* Fused RGB -> luma -> Sobel; the luma plane never touches HBM.  Same band semantics as above
- * (halo rows are RGB rows).  3 R + 1 W bytes per pixel. */
+ * (halo rows are RGB rows).  3 R + 1 W bytes per pixel.  Any width and alignment; the fast kernels need
+ * width % 16 == 0 and 16-byte aligned buffers, other frames run unaligned strips + a per-pixel column tail. */
 GH_API int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels,
                                         int mode, int top_is_border, int bottom_is_border, gh_stream_t stream);
 

@@ -97,8 +97,11 @@ __device__ __forceinline__ uint4 fused_row(stream_core::StateF2 &st, const uint3
 // R output rows per strip, C rows per load chunk
 template <int MODE, int CH, int R, int C, int ROLL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w,
-                                                                    int rows, int groups_x, int zero_top, int zero_bot)
+                                                                    int rows, int groups_x, int zero_top, int zero_bot, int ws)
 {
+    // w: frame width (row pitch = w * CH bytes; rows and buffers need not be 16-byte aligned: the vector accesses are then
+    // unaligned, which gfx950 global memory instructions handle); ws <= w, a multiple of 16: the columns covered by
+    // strips -- columns [ws, w) of a frame whose width is not a multiple of 16 are left to k_fused_px_cols.
     using namespace stream_core;
     static_assert(C % 2 == 0, "chunk must be even: the h2 ring slot is the row parity");
     constexpr int SLAB = STRIP_PX * CH;                          // bytes of one strip row
@@ -106,14 +109,15 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
     __shared__ __attribute__((aligned(16))) uint8_t slab[WAVES_PER_BLOCK][SLAB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx_i = (int)(blockIdx.x % (unsigned)groups_x), gy_i = (int)(blockIdx.x / (unsigned)groups_x);
-    const int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
-    if (xw >= w) return;
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;
+    if (xw >= ws) return;
+    if (xw + STRIP_PX > ws && ws >= STRIP_PX && ws < w) xw = ws - STRIP_PX;   // unaligned frames: last strip shifted left, all strips full
     const int x = xw + 16 * lane;
     const int y0 = gy_i * R;
     const f32x2 half2 = half2_reg();
-    const bool in_frame = x < w;
-    const bool full = xw + STRIP_PX <= w;
-    const int nvec = full ? NV * 64 : (w - xw) * CH / 16;                    // 16-byte vectors of this strip row inside the frame
+    const bool in_frame = x < ws;
+    const bool full = xw + STRIP_PX <= ws;
+    const int nvec = full ? NV * 64 : (ws - xw) * CH / 16;                    // 16-byte vectors of this strip row inside the frame
     // strip halo: lane 0 fetches the 16 bytes that END at the strip's first byte (pixel xw-1 is in there), lane 63 the 16
     // bytes that START after its last byte (pixel xw+1024).  One aligned dwordx4 per row for two lanes; nothing is
     // done with it until it is used, so it does not force an early s_waitcnt in the middle of the row loads.
@@ -152,7 +156,13 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
             }
         }
         hr = make_uint4(0, 0, 0, 0);
-        if (hvalid) hr = *reinterpret_cast<const uint4 *>(rowb + hoff);
+        if (hvalid) {
+            if (lane == 0 || (hx + 6) <= w) hr = *reinterpret_cast<const uint4 *>(rowb + hoff);      // 16 bytes = 5.3 (4) pixels: inside the row
+            else {                           // right halo pixel within the last 5 columns of an unaligned frame: no 16-byte read past the row
+                const uint8_t *q = rowb + hoff;
+                hr.x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+            }
+        }
     };
     if (ROLL) {
 #pragma unroll
@@ -189,6 +199,35 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_stream(const uint8
                 if (in_frame && y < rows) store_strip(edge + (size_t)y * w + xw, lane, out);
             }
         }
+    }
+}
+
+// Per-pixel form for what the strip kernels do not cover: the last w % 16 columns of a frame whose width is not a multiple
+// of 16, and frames narrower than 16 pixels (x0 = 0).  Same arithmetic: luma of the 3x3 neighbourhood, integer Sobel.
+template <int MODE>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_fused_px_cols(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows,
+                                                                     int ch, int x0, int zero_top, int zero_bot)
+{
+    const int nc = w - x0;
+    const size_t n = (size_t)nc * rows, stride = (size_t)gridDim.x * stream_core::BLOCK;
+    for (size_t i = (size_t)blockIdx.x * stream_core::BLOCK + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / nc), x = x0 + (int)(i - (size_t)y * nc);
+        uint32_t out = 0;
+        const bool border = x == 0 || x == w - 1 || (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
+        if (!border) {
+            int l[3][3];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const uint8_t *p = rgb + ((ptrdiff_t)(y + dy) * w + (x + dx)) * ch;
+                    l[dy + 1][dx + 1] = (int)gh_luma<MODE>(p[0], p[1], p[2]);
+                }
+            const int gx = -l[0][0] - 2 * l[1][0] - l[2][0] + l[0][2] + 2 * l[1][2] + l[2][2];
+            const int gy = l[0][0] + 2 * l[0][1] + l[0][2] - l[2][0] - 2 * l[2][1] - l[2][2];
+            out = gh_sobel_mag(gx * gx + gy * gy);
+        }
+        edge[(size_t)y * w + x] = (uint8_t)out;
     }
 }
 
@@ -385,16 +424,33 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
     if (width == 0 || rows == 0) return GH_OK;
     GH_REQUIRE(rgb && edge, "null pointer");
-    GH_REQUIRE(width % 16 == 0 && gh_aligned16(rgb) && gh_aligned16(edge),
-               "fused kernel needs width % 16 == 0 and 16-byte aligned buffers (use gh_gray_rgb8_to_plane_dev + gh_sobel_u8_rows_dev otherwise)");
     if (int rc = gh_ensure_init()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
-    static const bool use_tile = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
+    // Fast paths want 16-pixel columns and 16-byte aligned buffers.  Anything else: the register-staged strip kernel on the
+    // first ws = width & ~15 columns with unaligned vector accesses + the per-pixel kernel on the last width % 16 columns
+    // (large frames), or the per-pixel kernel alone (small ones).
+    const bool aligned = width % 16 == 0 && gh_aligned16(rgb) && gh_aligned16(edge);
+    const int ws = width & ~15;
+    auto launch_px_cols = [&](int x0) {
+        size_t blocks = ((size_t)(width - x0) * rows + stream_core::BLOCK - 1) / stream_core::BLOCK;
+        if (blocks > 8192) blocks = 8192;
+        if (mode == GH_MODE_FMA) k_fused_px_cols<GH_MODE_FMA><<<(unsigned)blocks, stream_core::BLOCK, 0, s>>>(rgb, edge, width, rows, channels, x0, zt, zb);
+        else k_fused_px_cols<GH_MODE_IEEE><<<(unsigned)blocks, stream_core::BLOCK, 0, s>>>(rgb, edge, width, rows, channels, x0, zt, zb);
+    };
+    // (unaligned strips need ws >= 1024: then every strip is full -- the last one is shifted left -- and the pixel right of
+    //  column ws - 1 arrives through lane 63's halo load; a ragged last strip would need column ws from beyond its loads)
+    if (!aligned && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
+        launch_px_cols(0);
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+    static const bool use_tile_env = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
+    const bool use_tile = use_tile_env && aligned;
     if (!use_tile) {
         const int variant = GH_TUNE_INT("GH_FUSED_VARIANT", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = (width + span - 1) / span;
+        const int groups_x = (ws + span - 1) / span;
         const unsigned b = stream_core::BLOCK;
 #define GH_FUSED_LAUNCH(R_, C_, RL_)                                                                                         \
         do {                                                                                                              \
@@ -402,11 +458,11 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");                                                \
             const unsigned g = (unsigned)nb;                                                                              \
             if (channels == 3) {                                                                                          \
-                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);  \
-                else k_fused_stream<GH_MODE_IEEE, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);                     \
+                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb, ws);  \
+                else k_fused_stream<GH_MODE_IEEE, 3, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb, ws);                     \
             } else {                                                                                                      \
-                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);  \
-                else k_fused_stream<GH_MODE_IEEE, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb);                     \
+                if (mode == GH_MODE_FMA) k_fused_stream<GH_MODE_FMA, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb, ws);  \
+                else k_fused_stream<GH_MODE_IEEE, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb, ws);                     \
             }                                                                                                             \
         } while (0)
         // LDS-DMA ring kernel.  Tuning found on MI355X (tools/ab_fused.py, 16384-wide frames):
@@ -417,7 +473,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
         //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
         //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
         int dma = GH_TUNE_INT("GH_FUSED_DMA", -1);         // ring depth D (0 = register-staged kernel, -1 = auto)
-        if (dma != 0 && width >= stream_core::STRIP_PX) {
+        if (dma != 0 && aligned && width >= stream_core::STRIP_PX) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
@@ -485,6 +541,10 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
         }
 #undef GH_FUSED_LAUNCH
         GH_LAUNCH_CHECK();
+        if (ws < width) {
+            launch_px_cols(ws);
+            GH_LAUNCH_CHECK();
+        }
         return GH_OK;
     }
     const int tiles_x = (width + TW - 1) / TW;

@@ -61,7 +61,7 @@ extern "C" int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsign
     GH_REQUIRE(channels == 3 || channels == 4, "streamed pipeline takes RGB8 or RGBA8");
     GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
     GH_REQUIRE(tile_rows >= 1, "tile_rows must be >= 1");
-    const bool two_kernels = width % 16 != 0;      // the fused kernel needs 16-pixel columns: such frames run gray -> plane Sobel per band
+    const bool two_kernels = false;                // (the fused entry point takes any width now; the two-kernel form is kept for reference)
     if (seconds) *seconds = 0.0;
     if (width == 0 || height == 0) return GH_OK;
     GH_REQUIRE(rgb && edge, "null pointer");

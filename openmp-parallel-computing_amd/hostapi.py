@@ -176,7 +176,8 @@ def sobel_rows(buf, out, rows: int, top_is_border: bool, bottom_is_border: bool)
 
 
 def gray_sobel_fused(rgb, mode: int = MODE_IEEE, out=None):
-    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane in one kernel (width % 16 == 0)."""
+    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane in one pass over the frame (any width; fastest when width % 16 == 0 and the
+    buffers are 16-byte aligned)."""
     import torch
     h, w, c = rgb.shape
     if out is None:
@@ -197,12 +198,8 @@ def gray_sobel_fused_rows(buf, out, rows: int, mode: int, top_is_border: bool, b
 
 
 def gray_sobel(rgb, mode: int = MODE_IEEE, out=None):
-    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane for ANY width: the fused kernel when the width is a multiple of 16 and the
-    buffers are 16-byte aligned, otherwise gray -> plane Sobel (two kernels, a temporary luma plane)."""
-    h, w, c = rgb.shape
-    if w % 16 == 0 and rgb.data_ptr() % 16 == 0 and (out is None or out.data_ptr() % 16 == 0):
-        return gray_sobel_fused(rgb, mode, out=out)
-    return sobel(gray_to_plane(rgb, mode), out=out)
+    """(h, w, c) RGB8/RGBA8 -> (h, w) edge plane, any width and alignment (alias of gray_sobel_fused)."""
+    return gray_sobel_fused(rgb, mode, out=out)
 
 
 def extract_plane(img, out=None):

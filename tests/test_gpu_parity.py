@@ -346,7 +346,7 @@ def test_error_paths(pkg, torch_mod):
     with pytest.raises(pkg.GrayHipError):
         pkg.hostapi.gray_to_plane(torch_mod.zeros((2, 2, 5), dtype=torch_mod.uint8, device="cuda"))
     with pytest.raises(pkg.GrayHipError):
-        pkg.hostapi.gray_sobel_fused(torch_mod.zeros((4, 10, 3), dtype=torch_mod.uint8, device="cuda"))
+        pkg.hostapi.gray_sobel_fused(torch_mod.zeros((4, 16, 2), dtype=torch_mod.uint8, device="cuda"))    # RGB8 / RGBA8 only
     empty = torch_mod.zeros((0, 16, 3), dtype=torch_mod.uint8, device="cuda")
     assert pkg.hostapi.gray_to_plane(empty).numel() == 0
 
@@ -552,6 +552,35 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
         assert np.array_equal(edge.cpu().numpy(), wants[0])
     finally:
         native_comm.set_loopback(False)
+
+
+@pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3)])
+def test_fused_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, c, monkeypatch):
+    """The fused C entry point takes any width: unaligned strips + per-pixel column tail (forced on for small frames here),
+    the per-pixel kernel alone, and unaligned buffer bases; whole frames and bands with real RGB halo rows."""
+    img = oracle.frame_rand(w, h, c, seed=w * 3 + h)
+    d = dev(torch_mod, img)
+    for min_px in ("1", str(1 << 30)):
+        monkeypatch.setenv("GH_FUSED_UNALIGNED_MIN_PX", min_px)
+        for mode in (0, 1):
+            want = oracle.sobel(oracle.gray_to_plane(img, mode))
+            assert np.array_equal(pkg.hostapi.gray_sobel_fused(d, mode).cpu().numpy(), want), (min_px, mode)
+            if h >= 3:
+                got = torch_mod.empty((h - 2, w), dtype=torch_mod.uint8, device="cuda")
+                pkg.hostapi.gray_sobel_fused_rows(d, got, h - 2, mode, False, False)
+                assert np.array_equal(got.cpu().numpy(), want[1:h - 1]), ("band", min_px, mode)
+    # width a multiple of 16, buffers at odd addresses; guard bytes around the output must stay untouched
+    monkeypatch.setenv("GH_FUSED_UNALIGNED_MIN_PX", "1")
+    w2 = (w + 15) & ~15
+    img2 = oracle.frame_rand(w2, h, c, seed=w2)
+    raw_in = torch_mod.zeros(h * w2 * c + 32, dtype=torch_mod.uint8, device="cuda")
+    raw_out = torch_mod.zeros(h * w2 + 32, dtype=torch_mod.uint8, device="cuda")
+    src = raw_in[7:7 + h * w2 * c].view(h, w2, c)
+    dst = raw_out[3:3 + h * w2].view(h, w2)
+    src.copy_(dev(torch_mod, img2))
+    pkg.hostapi.gray_sobel_fused(src, 0, out=dst)
+    assert np.array_equal(dst.cpu().numpy(), oracle.sobel(oracle.gray_to_plane(img2, 0)))
+    assert not raw_out[:3].any() and not raw_out[3 + h * w2:].any()
 
 
 def test_gray_sobel_any_width(pkg, oracle, torch_mod):
