@@ -133,8 +133,7 @@ GH_API int gh_sum_rgb8_host(const unsigned char *rgb, size_t npix, uint64_t sums
  * (BASELINE configs[4]: 65536x65536 streamed tiles).  The frame is cut into bands of `tile_rows` rows (+ one RGB halo
  * row above and below, re-sent with each band, so bands are independent); three hipStreams and a 3-slot ring of
  * device buffers overlap H2D of band k+1, the fused kernel on band k and D2H of band k-1.  Output: the 1 B/px edge
- * plane (frame border = 0), identical to gh_gray_sobel_fused_rows_dev on the whole frame (widths that are not a multiple
- * of 16 run gray -> plane Sobel per band instead of the fused kernel; same result).  Overlap is real only if
+ * plane (frame border = 0), identical to gh_gray_sobel_fused_rows_dev on the whole frame (any width).  Overlap is real only if
  * the host buffers are page-locked: pass host_buffers_pinned != 0 if they already are (hipHostMalloc /
  * hipHostRegister / torch pin_memory), 0 to let the call register and unregister them itself.
  * seconds (optional) = wall time of the pipelined loop, registration excluded.  PCIe-bound by construction. */

@@ -17,7 +17,6 @@ constexpr int NSLOT = 3;
 struct Ring {
     uint8_t *rgb[NSLOT] = {nullptr, nullptr, nullptr};
     uint8_t *edge[NSLOT] = {nullptr, nullptr, nullptr};
-    uint8_t *luma[NSLOT] = {nullptr, nullptr, nullptr};    // only for widths the fused kernel does not take (width % 16 != 0)
     hipEvent_t uploaded[NSLOT] = {}, computed[NSLOT] = {}, downloaded[NSLOT] = {};
     hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
     bool reg_in = false, reg_out = false;
@@ -29,7 +28,6 @@ struct Ring {
         for (int i = 0; i < NSLOT; ++i) {
             if (rgb[i]) (void)hipFree(rgb[i]);
             if (edge[i]) (void)hipFree(edge[i]);
-            if (luma[i]) (void)hipFree(luma[i]);
             if (uploaded[i]) (void)hipEventDestroy(uploaded[i]);
             if (computed[i]) (void)hipEventDestroy(computed[i]);
             if (downloaded[i]) (void)hipEventDestroy(downloaded[i]);
@@ -61,7 +59,6 @@ extern "C" int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsign
     GH_REQUIRE(channels == 3 || channels == 4, "streamed pipeline takes RGB8 or RGBA8");
     GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
     GH_REQUIRE(tile_rows >= 1, "tile_rows must be >= 1");
-    const bool two_kernels = false;                // (the fused entry point takes any width now; the two-kernel form is kept for reference)
     if (seconds) *seconds = 0.0;
     if (width == 0 || height == 0) return GH_OK;
     GH_REQUIRE(rgb && edge, "null pointer");
@@ -86,7 +83,6 @@ extern "C" int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsign
     for (int i = 0; i < NSLOT; ++i) {
         GH_HIP_TRY(hipMalloc(&r.rgb[i], row_in * (tile_rows + 2)));
         GH_HIP_TRY(hipMalloc(&r.edge[i], row_out * tile_rows));
-        if (two_kernels) GH_HIP_TRY(hipMalloc(&r.luma[i], row_out * (tile_rows + 2)));
         GH_HIP_TRY(hipEventCreateWithFlags(&r.uploaded[i], hipEventDisableTiming));
         GH_HIP_TRY(hipEventCreateWithFlags(&r.computed[i], hipEventDisableTiming));
         GH_HIP_TRY(hipEventCreateWithFlags(&r.downloaded[i], hipEventDisableTiming));
@@ -110,18 +106,9 @@ extern "C" int gh_gray_sobel_streamed_rows_host(const unsigned char *rgb, unsign
         GH_HIP_TRY(hipEventRecord(r.uploaded[slot], r.s_in));
         // compute
         GH_HIP_TRY(hipStreamWaitEvent(r.s_comp, r.uploaded[slot], 0));
-        if (!two_kernels) {
-            if (int rc = gh_gray_sobel_fused_rows_dev(r.rgb[slot] + row_in, r.edge[slot], width, rows, channels, mode, top ? 1 : 0,
-                                                      bot ? 1 : 0, r.s_comp))
-                return rc;
-        } else {
-            // luma of the band rows and of the halo rows that exist, then the band Sobel on the luma plane
-            const int lo = top ? 1 : 0, n = rows + (top ? 0 : 1) + (bot ? 0 : 1);
-            if (int rc = gh_gray_rgb8_to_plane_dev(r.rgb[slot] + (size_t)lo * row_in, r.luma[slot] + (size_t)lo * row_out, (size_t)n * width, channels,
-                                                   mode, r.s_comp))
-                return rc;
-            if (int rc = gh_sobel_u8_rows_dev(r.luma[slot] + row_out, r.edge[slot], width, rows, top ? 1 : 0, bot ? 1 : 0, r.s_comp)) return rc;
-        }
+        if (int rc = gh_gray_sobel_fused_rows_dev(r.rgb[slot] + row_in, r.edge[slot], width, rows, channels, mode, top ? 1 : 0,
+                                                  bot ? 1 : 0, r.s_comp))
+            return rc;
         GH_HIP_TRY(hipEventRecord(r.computed[slot], r.s_comp));
         // D2H
         GH_HIP_TRY(hipStreamWaitEvent(r.s_out, r.computed[slot], 0));
