@@ -26,6 +26,9 @@ while time.time() < t_end:
     for k in allk: os.environ.pop(k, None)
     os.environ.update(knob_sets[rnd.randint(len(knob_sets))])
     w = 16 * int(rnd.randint(64, 520)); h = int(rnd.choice([1, 2, 3, 17, 63, 64, 65, 66, 127, 130, 257, 300])); ch = int(rnd.choice([3, 3, 4]))
+    if rnd.randint(4) == 0:                              # widths that are not multiples of 16: unaligned strips + column tail
+        w += int(rnd.randint(1, 16))
+        os.environ["GH_FUSED_UNALIGNED_MIN_PX"] = os.environ["GH_SOBEL_UNALIGNED_MIN_PX"] = "1"
     mode = int(rnd.randint(2))
     img = O.frame_rand(w, h, ch, seed=int(rnd.randint(1 << 30)))
     d = torch.from_numpy(img).cuda()
