@@ -209,8 +209,12 @@ int gh_pipeline_gray_sobel_dev(uint8_t *img, int width, int height, int channels
     GH_REQUIRE(img && gray_ws && edge_ws, "null pointer");
     for (int p = 0; p < passes; ++p) {
         int rc;
-        if (p == 0) {
-            // gray in place + extract fused: the in-place luma write is dead, replicate overwrites R,G,B
+        if (p == 0 && channels >= 3) {
+            // pass 1 in ONE kernel: RGB -> luma -> Sobel (the in-place luma write of the reference is dead: replicate overwrites
+            // R,G,B; the luma plane is not needed afterwards -- later passes start from the edge plane)
+            if ((rc = gh_gray_sobel_fused_rows_dev(img, edge_ws, width, height, channels, mode, 1, 1, stream))) return rc;
+            continue;
+        } else if (p == 0) {
             rc = gh_gray_rgb8_to_plane_dev(img, gray_ws, npix, channels, mode, stream);
         } else if (channels >= 3) {
             // the image now holds (e,e,e): its luma is lum(e,e,e), not e (13 grey levels move in IEEE mode)
