@@ -119,7 +119,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // but the prefetch depth costs LDS (1 KiB per row and wave) instead of registers, so it can be deep: the plane kernel
 // moves only 2 B/px, a wave's row is consumed in ~550 cycles and the register-staged form cannot keep enough bytes
 // in flight at 3 waves per SIMD.  The last strip of a row is shifted left to end at the frame edge (all strips full).
-template <int D, int PROBE = 0>
+template <int D, int PROBE = 0, int SP = 2>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
                     if (x == 0) out.x &= 0xffffff00u;
                     if (x + 15 == w - 1) out.w &= 0x00ffffffu;
                     if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                    store_strip(dst + (size_t)y * w + xw, lane, out);
+                    store_strip_p<SP>(dst + (size_t)y * w + xw, lane, out);
                 }
             }
         }
@@ -372,15 +372,21 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
             
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
-            if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            // Output store policy.  For this 1 R : 1 W kernel `sc1` buffer stores are worth 12 % over nontemporal ones
+            // (16384^2, 21 interleaved rounds: sc1 74.7 %, plain 72 %, nt 66.7 % of 8 TB/s; shards: equal or better) -- the
+            // opposite of the 3 R : 1 W fused kernel, where nt wins (72.5 % vs 68 % sc1 vs 66 % plain).
+            const int sp = GH_TUNE_INT("GH_SOBEL_ST", 1);        // 1 sc1 (default), 0 plain, 2 nt
+            if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt (wrong results)
 #endif
-            else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 2) k_sobel_dma<2, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma <= 6) k_sobel_dma<6><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else k_sobel_dma<8><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 4) k_sobel_dma<4, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 6) k_sobel_dma<6, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else k_sobel_dma<8, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             GH_LAUNCH_CHECK();
             return GH_OK;
         }
