@@ -372,21 +372,22 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
             
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
-            // Output store policy.  For this 1 R : 1 W kernel `sc1` buffer stores are worth 12 % over nontemporal ones
-            // (16384^2, 21 interleaved rounds: sc1 74.7 %, plain 72 %, nt 66.7 % of 8 TB/s; shards: equal or better) -- the
-            // opposite of the 3 R : 1 W fused kernel, where nt wins (72.5 % vs 68 % sc1 vs 66 % plain).
-            const int sp = GH_TUNE_INT("GH_SOBEL_ST", 1);        // 1 sc1 (default), 0 plain, 2 nt
+            // Output store policy: nontemporal.  sc1 / plain stores LOOK 8-12 % faster when the same 268 MB output plane is
+            // rewritten launch after launch (74.7 % vs 66.7 %): the 256 MB Infinity Cache absorbs the writes and they never
+            // reach HBM.  With the output rotating over six planes it is the other way round (sc1 62.6 %, plain 60.7 %,
+            // nt 66.8 %; tools/ab_fused.py --out-ring 6), and nt performs the same in both settings.
+            const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
             if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt (wrong results)
 #endif
-            else if (dma <= 2) k_sobel_dma<2, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 4) k_sobel_dma<4, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma <= 6) k_sobel_dma<6, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else k_sobel_dma<8, 0, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 6) k_sobel_dma<6><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else k_sobel_dma<8><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             GH_LAUNCH_CHECK();
             return GH_OK;
         }

@@ -212,12 +212,26 @@ __device__ __forceinline__ uint4 load_stream(const uint4 *p)
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void store_stream(uint4 *p, const uint4 v)
+// Streaming stores.  POLICY 2 = nontemporal (what every kernel uses), 1 = sc1, 0 = plain.
+// A trap worth a comment: measured in a loop that rewrites ONE 268 MB output plane, sc1 / plain stores look much faster for the
+// kernels that write a single plane (RGB -> plane 88.6 % vs 78.9 % nt, extract 89 % vs 78 %, plane Sobel 74.7 % vs 66.7 %) --
+// the 256 MB Infinity Cache absorbs the writes, which are overwritten before they ever reach HBM.  With the output rotating
+// over six planes (1.6 GB) the order flips (RGB -> plane: sc1 77.4 %, nt 79.1 %; Sobel: sc1 62.6 %, nt 66.8 %) and the
+// next kernel of a pipeline pays for the deferred write-backs (gray -> Sobel back to back: 0.88 instead of 0.99 Tpixel/s).
+// Nontemporal stores perform the same in both settings: they are the honest, steady-state choice.
+#ifndef GH_STREAM_STORE_POLICY
+#define GH_STREAM_STORE_POLICY 2
+#endif
+template <int POLICY>
+__device__ __forceinline__ void store_stream_p(uint4 *p, const uint4 v)
 {
     u32x4 t;
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+    if (POLICY == 2) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+    else if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+    else *reinterpret_cast<u32x4 *>(p) = t;
 }
+__device__ __forceinline__ void store_stream(uint4 *p, const uint4 v) { store_stream_p<GH_STREAM_STORE_POLICY>(p, v); }
 
 // ---- wave-level RGB8 de-interleave through a private 3 KiB LDS slab ---------------------------------------
 // A wavefront owns 1024 consecutive pixels = 3072 bytes = 192 dwordx4.  Loading 48 B per lane directly touches every

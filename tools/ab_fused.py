@@ -15,6 +15,8 @@ ap.add_argument("--op", default="fused"); ap.add_argument("--w", type=int, defau
 ap.add_argument("--rounds", type=int, default=9); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--in-offset-rows", type=int, default=0, help="input frame starts this many rows into its allocation")
 ap.add_argument("--out-offset-rows", type=int, default=0, help="output plane starts this many rows into its allocation")
+ap.add_argument("--out-ring", type=int, default=1, help="rotate the output over this many buffers (a single 268 MB output plane fits the 256 MB Infinity Cache: write-back stores can then look faster than HBM allows)")
+ap.add_argument("--in-ring", type=int, default=1, help="rotate the input over this many frames (defeats any Infinity Cache read hits between launches)")
 ap.add_argument("variants", nargs="*")
 a = ap.parse_args()
 W, H = a.w, (a.h or a.w)
@@ -40,6 +42,17 @@ ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (la
        "minmax": (lambda: pkg.abi.check(pkg.abi.load().gh_mean_gray_minmax_dev(rgb.data_ptr(), out3.data_ptr(), W * H, mm.data_ptr(), torch.cuda.current_stream().cuda_stream)), 6),
        "sum": (lambda: pkg.abi.check(pkg.abi.load().gh_sum_rgb8_dev(rgb.data_ptr(), W * H, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)), 3)}
 fn, bpp = ops[a.op]
+if (a.out_ring > 1 or a.in_ring > 1) and a.op in ("fused", "sobel", "gray", "extract", "grayplane"):
+    outs = [out] + [torch.empty((H, W), dtype=torch.uint8, device="cuda") for _ in range(a.out_ring - 1)]
+    rgbs = [rgb] + [rgb.clone() for _ in range(a.in_ring - 1)] if a.op in ("fused", "gray", "extract") else [rgb]
+    planes = [plane] + [plane.clone() for _ in range(a.in_ring - 1)] if a.op in ("sobel", "grayplane") else [plane]
+    cnt = [0]
+    base_ops = {"fused": lambda i, o: api.gray_sobel_fused(rgbs[i % len(rgbs)], 0, out=o), "sobel": lambda i, o: api.sobel(planes[i % len(planes)], out=o),
+                "gray": lambda i, o: api.gray_to_plane(rgbs[i % len(rgbs)], 0, out=o), "extract": lambda i, o: api.extract_plane(rgbs[i % len(rgbs)], out=o),
+                "grayplane": lambda i, o: api.gray_of_plane(planes[i % len(planes)], 0, out=o)}[a.op]
+    def fn():
+        cnt[0] += 1
+        base_ops(cnt[0], outs[cnt[0] % len(outs)])
 variants = [("base", {})]
 for v in a.variants:
     name, _, kv = v.partition("=")
