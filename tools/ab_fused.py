@@ -42,6 +42,15 @@ ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (la
        "minmax": (lambda: pkg.abi.check(pkg.abi.load().gh_mean_gray_minmax_dev(rgb.data_ptr(), out3.data_ptr(), W * H, mm.data_ptr(), torch.cuda.current_stream().cuda_stream)), 6),
        "sum": (lambda: pkg.abi.check(pkg.abi.load().gh_sum_rgb8_dev(rgb.data_ptr(), W * H, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)), 3)}
 fn, bpp = ops[a.op]
+if a.in_ring > 1 and a.op in ("sum", "minmax"):
+    rgbs = [rgb] + [rgb.clone() for _ in range(a.in_ring - 1)]
+    cnt = [0]
+    L = pkg.abi.load()
+    def fn():
+        cnt[0] += 1
+        r = rgbs[cnt[0] % len(rgbs)]
+        if a.op == "sum": pkg.abi.check(L.gh_sum_rgb8_dev(r.data_ptr(), W * H, sums.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        else: pkg.abi.check(L.gh_mean_gray_minmax_dev(r.data_ptr(), out3.data_ptr(), W * H, mm.data_ptr(), torch.cuda.current_stream().cuda_stream))
 if (a.out_ring > 1 or a.in_ring > 1) and a.op in ("fused", "sobel", "gray", "extract", "grayplane"):
     outs = [out] + [torch.empty((H, W), dtype=torch.uint8, device="cuda") for _ in range(a.out_ring - 1)]
     rgbs = [rgb] + [rgb.clone() for _ in range(a.in_ring - 1)] if a.op in ("fused", "gray", "extract") else [rgb]
