@@ -5,26 +5,40 @@ synthetic 16384 x 16384 frame (BASELINE.json configs[2]; row-sharded over N GPUs
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` (N > 1) without a torch.distributed environment starts its N ranks itself: the parent process, which
+never touches the GPU, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD and relays
+rank 0's JSON line and the exit code.
+
 One "step" = one pass of the hot path over one frame that is already resident in HBM:
     --pipeline fused (default): ONE kernel, RGB -> luma -> Sobel edge plane, 3 R + 1 W bytes per pixel
                                 (the luma plane never leaves the chip);
     --pipeline split          : gray_rgb8_to_plane (3 R + 1 W B/px) then sobel3x3_u8 (1 R + 1 W B/px).
-With N > 1 the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with
-each neighbour over RCCL (torch.distributed P2P): an RGB row for the fused pipeline, a luma row for the
-split one -- overlapped with the interior rows, which do not depend on it.
+N = 1: `value` comes from K steps of the chosen pipeline; a second timed region of K steps of the OTHER pipeline follows,
+so that every headline kernel (fused, RGB -> gray, plane Sobel) has a HIP-event figure measured inside a timed region.
+N > 1: the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with each neighbour over
+RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three step forms are timed, each with the
+contract's bracket (barrier + synchronize on both sides, MAX over ranks):
+    pipelined     a stream of frames in a ring of three buffers; the halo of frame k+2 travels while frame k runs as one
+                  launch (`value`, as in round 1);
+    single_frame  ONE frame, strong-scaled: exchange || interior rows, then the first and last row (BASELINE configs[3]
+                  as written: the latency of one sharded frame);
+    end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory.
 Every kernel is the hand-written gfx950 code in libgrayhip.so, called through its C ABI; torch is only
 the allocator, the stream provider and the process group.
 
 Prints ONE JSON line on rank 0: Mpixels/s over the whole job, the HBM roofline fraction of the dominant
-kernel (HIP-event timed inside the timed region), a per-kernel table, and the reference's OpenMP CPU
-path timed on this box's host cores (a reported baseline, not the target).
+kernel (HIP-event timed inside the timed region), a per-kernel table, the measured copy ceiling of this GPU and the
+reference's OpenMP CPU path timed on this box's host cores (a reported baseline, not the target).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,13 +46,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6600 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the achievable rate is measured live (copy_ceiling_GBs)
 ALGO_BYTES_PER_PX = {          # each image byte counted once
     "gray_sobel_fused_rgb8": 4,  # 3 R + 1 W
     "gray_rgb8_to_plane": 4,     # 3 R + 1 W
     "sobel3x3_u8": 2,            # 1 R + 1 W
     "gray_inplace_rgb8": 6,      # 3 R + 3 W (the reference ABI's in-place form)
 }
+M64 = (1 << 64) - 1
 
 
 def parse_args():
@@ -58,9 +73,9 @@ def parse_args():
                          "or by torch.distributed P2P ops from Python (torch); native falls back to torch if it cannot be set up "
                          "or disagrees with it on the first frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel measurements after the timed region")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16384, help="rows of the frame the CPU baseline is timed on (default: the whole 16384^2 frame, ~25 core-seconds of work)")
-    ap.add_argument("--no-check", action="store_true", help="skip the post-run parity spot check against the oracle")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the second timed region and the per-kernel measurements")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="wall-clock budget of the CPU baseline matrix")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run parity checks")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed run-in before the W warm-up steps: after ~2 ms of load the GPU's power management dips the clocks and "
                          "takes 30-60 ms to settle (tools/drift_start.py: launches 10-40 of a burst run 25-40 %% slower); "
@@ -68,10 +83,71 @@ def parse_args():
     return ap.parse_args()
 
 
+# ---- N > 1 from the plain command: start the ranks as children --------------------------------------------------------
+
+def self_launch(n: int) -> int:
+    """`bench.py --gpus N` outside torch.distributed.run: this process has not touched the GPU (torch is not even
+    imported) and stays that way; the ranks are children of a child."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")                # what torchrun would set anyway (and says so on stderr)
+    print(f"bench.py: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode        # stdout is inherited: rank 0 writes the JSON line to it
+
+
+# ---- synthetic frames: SURVEY.md section 8(c) rand(seed), i.e. the SplitMix64 output stream, generated ON the GPU -------
+
+def _s64(v: int) -> int:
+    v &= M64
+    return v - (1 << 64) if v >> 63 else v
+
+
+def splitmix_bytes(torch, device, byte0: int, nbytes: int, seed: int):
+    """Bytes [byte0, byte0 + nbytes) of rand(seed) as a uint8 tensor (byte0 and nbytes multiples of 8).
+    int64 arithmetic wraps mod 2^64 on the device; >> is arithmetic, so logical shifts mask the sign copies off."""
+    assert byte0 % 8 == 0 and nbytes % 8 == 0
+    out = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    words = out.view(torch.int64)
+    chunk = 1 << 24
+    lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
+    for w0 in range(0, nbytes // 8, chunk):
+        n = min(chunk, nbytes // 8 - w0)
+        j = torch.arange(byte0 // 8 + w0 + 1, byte0 // 8 + w0 + 1 + n, dtype=torch.int64, device=device)
+        z = j * _s64(0x9E3779B97F4A7C15) + _s64(seed)
+        z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+        words[w0:w0 + n] = z ^ lsr(z, 31)
+    return out
+
+
+def known_answers():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+    except Exception:
+        return {}
+
+
+def sha256_of(t) -> str:
+    h = hashlib.sha256()
+    flat = t.reshape(-1)
+    step = 1 << 28
+    for i in range(0, flat.numel(), step):
+        h.update(flat[i:i + step].cpu().numpy().data)
+    return h.hexdigest()
+
+
+# ---- committed PMC evidence ---------------------------------------------------------------------------------------------
+
 def measured_traffic(kernel_name: str, px: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic.json:
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/<LATEST>/pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction), scaled to this launch's
-    pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself."""
+    pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself.  A summary whose
+    two passes averaged very different numbers of launches (an outlier filter gone wrong) is refused."""
     sym = {"gray_sobel_fused_rgb8": ("k_fused_dma", "k_fused_stream"), "gray_rgb8_to_plane": ("k_gray_rgb_to_plane_w",),
            "sobel3x3_u8": ("k_sobel_dma", "k_sobel_stream")}
     try:
@@ -81,72 +157,173 @@ def measured_traffic(kernel_name: str, px: int):
         for name in sym[kernel_name]:
             k = kernels.get(name)
             if k and "hbm_total_bytes" in k:
+                n = k.get("launches_averaged", [0, 0])
+                if min(n) < 1 or max(n) > 10 * min(n):
+                    return None, f"{os.path.relpath(f, ROOT)} refused: launches averaged {n}"
                 return int(k["hbm_total_bytes"] / (16384 * 16384) * px), os.path.relpath(f, ROOT)
     except Exception:
         pass
     return None, None
 
 
-def cpu_baseline(width: int, sample_rows: int) -> dict:
-    """The reference's OpenMP CPU path on this box's host cores, kernel-only timing (clock around the calls like
-    monolithic/src/main.c:30-38), on a bounded sample: the first `sample_rows` rows of the frame.  Uses the
-    reference's own sources compiled in place (oracle/_ref/libref_ieee.so, kind "reference") when that prebuilt
-    file travelled with the repo, otherwise this repo's C restatement (oracle/liboracle.so, kind "port")."""
+# ---- the reference's CPU path on this box's host cores ------------------------------------------------------------------
+
+def host_topology() -> dict:
+    """Logical CPUs this process may run on, the physical cores among them (one logical CPU per (package, core id), as
+    `lscpu` counts them -- bench_and_plot_monolithic.sh:12), the cgroup CPU quota if there is one, and the CPU model."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            key = (open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip())
+        except OSError:
+            key = ("?", str(c))
+        cores.setdefault(key, c)
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"logical": len(allowed), "physical": len(cores), "cgroup_cpus": quota, "model": model,
+            "first_cpu_of_each_core": sorted(cores.values())}
+
+
+def cpu_has(*flags) -> bool:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                have = set(line.split(":", 1)[1].split())
+                return all(f in have for f in flags)
+    except OSError:
+        pass
+    return False
+
+
+def cpu_baseline(width: int, height: int, budget_s: float) -> dict:
+    """SURVEY.md section 8(d) matrix: {1 thread, all physical cores} x {service flags `-O3 -fopenmp`
+    (microservices/grayscale/c/Makefile:2), monolithic flags `-O3 -ffast-math -funroll-loops -fopenmp`
+    (monolithic/Makefile:2; built for x86-64-v3 instead of -march=native so that the file runs on another host)},
+    kernel-only timing around the calls like monolithic/src/main.c:30-38, best of 5 with the spread.
+    The code timed is the reference's own parallel_to_grayscale.c + sobel.c compiled where they lie (oracle/_ref/*.so,
+    kind "reference") when those prebuilt files travelled with the repo, otherwise this repo's C restatement (kind "port").
+    OMP_PLACES=cores / OMP_PROC_BIND=close were exported at the top of main(), before any OpenMP runtime was loaded; the frame
+    is first-touched by the same static partition of threads that later processes it.  The all-cores cells run on the whole
+    frame, the 1-thread cells on a row sample so that the matrix stays inside its time budget."""
     import ctypes as C
 
     import numpy as np
     from oracle import pyoracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    npix = width * sample_rows
-    img0 = O.frame_rand(width, sample_rows, 3, seed=1)
-    kind = "reference" if O.have_ref("ieee") else "port"
+
+    t_end = time.time() + budget_s
+    topo = host_topology()
+    nthreads_all = topo["physical"]
+    if topo["cgroup_cpus"]:
+        nthreads_all = max(1, min(nthreads_all, int(topo["cgroup_cpus"])))
+    gomp = C.CDLL("libgomp.so.1")
+    L = O.lib()
     u8p = C.POINTER(C.c_uint8)
-    if kind == "reference":
-        ref = O.RefLib("ieee")
+    libs = {}
+    if O.have_ref("ieee"):
+        libs["service flags (-O3 -fopenmp)"] = ("reference", O.RefLib("ieee").L)
+    fast = os.path.join(O.REF_DIR, "libref_fast_v3.so")
+    if os.path.exists(fast) and cpu_has("avx2", "fma", "bmi2"):
+        lib = C.CDLL(fast)
+        lib.convert_to_grayscale.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+        lib.sobel_edge.argtypes = [u8p, u8p, C.c_int, C.c_int]
+        libs["monolithic flags (-O3 -march=x86-64-v3 -ffast-math -funroll-loops -fopenmp)"] = ("reference", lib)
+    if not libs:
+        class Port:      # this repo's restatement behind the reference's two prototypes
+            @staticmethod
+            def convert_to_grayscale(p, w, h, c):
+                L.orc_gray_inplace(p, w, h, c, O.MODE_IEEE)
 
-        def run_gray(buf):
-            ref.L.convert_to_grayscale(buf.ctypes.data_as(u8p), width, sample_rows, 3)
+            @staticmethod
+            def sobel_edge(s, d, w, h):
+                L.orc_sobel_interior(s, d, w, h)
+        libs["port (-O3 -fopenmp -ffp-contract=off)"] = ("port", Port)
 
-        def run_sobel(src, dst):
-            ref.L.sobel_edge(src.ctypes.data_as(u8p), dst.ctypes.data_as(u8p), width, sample_rows)
-    else:
-        L = O.lib()
+    def make_frame(rows, threads):
+        gomp.omp_set_num_threads(threads)
+        n = width * rows * 3
+        img = np.empty(n, dtype=np.uint8)                   # untouched pages ...
+        L.orc_fill_rand(img.ctypes.data_as(u8p), n, 1)      # ... first-touched by the static partition of `threads` threads
+        plane = np.empty(width * rows, dtype=np.uint8)
+        L.orc_gray_to_plane(img.ctypes.data_as(u8p), plane.ctypes.data_as(u8p), width, rows, 3, O.MODE_IEEE)
+        edge = np.empty(width * rows, dtype=np.uint8)
+        L.orc_gray_to_plane(img.ctypes.data_as(u8p), edge.ctypes.data_as(u8p), width, rows, 3, O.MODE_IEEE)   # first touch of dst
+        return img, plane, edge
 
-        def run_gray(buf):
-            L.orc_gray_inplace(buf.ctypes.data_as(u8p), width, sample_rows, 3, O.MODE_IEEE)
+    def time_cell(lib, rows, threads, frame, deadline):
+        img, plane, edge = frame
+        gomp.omp_set_num_threads(threads)
+        tg, ts = [], []
+        for rep in range(6):
+            t0 = time.perf_counter()
+            lib.convert_to_grayscale(img.ctypes.data_as(u8p), width, rows, 3)      # in place; later reps see grey input: same work
+            t1 = time.perf_counter()
+            lib.sobel_edge(plane.ctypes.data_as(u8p), edge.ctypes.data_as(u8p), width, rows)
+            t2 = time.perf_counter()
+            if rep:                                                                # first repetition = warm-up
+                tg.append(t1 - t0)
+                ts.append(t2 - t1)
+            if time.time() > deadline and len(tg) >= 2:
+                break
+        npx = width * rows
+        best = min(g + s for g, s in zip(tg, ts))
+        worst = max(g + s for g, s in zip(tg, ts))
+        return {"threads": threads, "rows": rows, "Mpixels/s": round(npx / best / 1e6, 1), "worst_Mpixels/s": round(npx / worst / 1e6, 1),
+                "gray_Mpixels/s": round(npx / min(tg) / 1e6, 1), "sobel_Mpixels/s": round(npx / min(ts) / 1e6, 1), "reps": len(tg)}
 
-        def run_sobel(src, dst):
-            L.orc_sobel_interior(src.ctypes.data_as(u8p), dst.ctypes.data_as(u8p), width, sample_rows)
-
-    plane = np.ascontiguousarray(O.gray_to_plane(img0, O.MODE_IEEE))
-    edge = np.zeros_like(plane)
-    best_g, best_s = float("inf"), float("inf")
-    t_budget = time.time() + 25.0
-    reps = 0
-    while reps < 6 and time.time() < t_budget:
-        buf = img0.copy()
-        t0 = time.perf_counter(); run_gray(buf); t1 = time.perf_counter()
-        run_sobel(plane, edge); t2 = time.perf_counter()
-        if reps > 0:   # first repetition is the warm-up
-            best_g, best_s = min(best_g, t1 - t0), min(best_s, t2 - t1)
-        reps += 1
+    rows1 = min(height, 2048)                     # 1-thread sample: 33.5 Mpx, ~0.25 s per repetition
+    matrix, kind = {}, "port"
+    share = max((t_end - time.time()) / (2 * len(libs)), 1.0)
+    frame_all = make_frame(height, nthreads_all)
+    for name, (k, lib) in libs.items():
+        kind = k
+        matrix[f"{name}, {nthreads_all} threads"] = time_cell(lib, height, nthreads_all, frame_all, time.time() + share)
+    del frame_all
+    if nthreads_all > 1:
+        frame_one = make_frame(rows1, 1)
+        for name, (k, lib) in libs.items():
+            matrix[f"{name}, 1 thread"] = time_cell(lib, rows1, 1, frame_one, time.time() + share)
+    head_key = next(iter(matrix))                  # service flags on all physical cores: what images/test_gray.png was made with
+    head = matrix[head_key]
     return {
-        "value": round(npix / (best_g + best_s) / 1e6, 1),
+        "value": head["Mpixels/s"],
         "unit": "Mpixels/s",
-        "cores": int(os.environ["OMP_NUM_THREADS"]),
+        "cores": nthreads_all,
         "kind": kind,
-        "sample": (f"the whole {width}x{sample_rows} rand(seed=1) frame" if sample_rows >= 16384 else
-                   f"first {sample_rows} rows of the {width}-wide rand(seed=1) frame") + f" ({npix / 1e6:.0f} Mpx), "
-                  f"convert_to_grayscale + sobel_edge, kernel-only, best of {max(reps - 1, 1)}, flags -O3 -fopenmp",
-        "gray_mpix_s": round(npix / best_g / 1e6, 1),
-        "sobel_mpix_s": round(npix / best_s / 1e6, 1),
+        "sample": f"the whole {width}x{height} rand(seed=1) frame ({width * height / 1e6:.0f} Mpx) for the all-cores cells, its first {rows1} rows "
+                  f"for the 1-thread cells; convert_to_grayscale + sobel_edge, kernel-only, best of 5 (worst also given); "
+                  f"value = {head_key}",
+        "matrix": matrix,
+        "host": {k: topo[k] for k in ("logical", "physical", "cgroup_cpus", "model")},
+        "omp": {"OMP_PLACES": os.environ.get("OMP_PLACES"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND")},
     }
 
 
 def main() -> int:
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     # stdout carries exactly ONE line, the JSON: libraries print banners to file descriptor 1 (RCCL's version block when a
     # communicator is created, gloo's connection notes), so everything else is sent to stderr from here on
     sys.stdout.flush()
@@ -156,11 +333,11 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
-                  f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}", file=sys.stderr)
-            return 2
         args.gpus = world
+    if world == 1:
+        # the CPU baseline's thread placement must be in the environment before ANY OpenMP runtime is loaded (torch brings one)
+        os.environ.setdefault("OMP_PLACES", "cores")
+        os.environ.setdefault("OMP_PROC_BIND", "close")
 
     import torch
     import torch.distributed as dist
@@ -189,6 +366,7 @@ def main() -> int:
     pkg = importlib.import_module("openmp-parallel-computing_amd")
     api, sharding = pkg.hostapi, pkg.sharding
     api.init(local_rank)
+    lib = pkg.abi.load()
     mode = pkg.MODE_FMA if args.mode == "fma" else pkg.MODE_IEEE
 
     W = args.width
@@ -199,15 +377,58 @@ def main() -> int:
     fused = args.pipeline == "fused"
     overlap = not args.no_overlap
     backend = sharding.HipBackend(mode)
+    stream = torch.cuda.current_stream()
+    single = world == 1
+    px_rank = rows * W
 
     def all_ranks_agree(flag: bool) -> bool:
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn, k_steps, events=None):
+        """The contract's bracket: barrier + synchronize, EXACTLY k_steps steps, barrier + synchronize; MAX over ranks.
+        Returns (seconds, host seconds spent enqueueing)."""
+        fence()
+        t0 = time.perf_counter()
+        for k in range(k_steps):
+            step_fn(k, events[k] if events else None)
+        host = time.perf_counter() - t0
+        fence()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), host
+
+    def run_in(step_fn):
+        if args.settle_ms > 0:       # run-in (untimed, before the warm-up steps): let the clocks settle under this very load
+            t_end = time.perf_counter() + args.settle_ms * 1e-3
+            k = 0
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    step_fn(k, None)
+                    k += 1
+                torch.cuda.synchronize()
+        for k in range(args.warmup):
+            step_fn(k, None)
+
+    # ranks that really met: one all-reduce of a 1 over the process group, and (native path) one over libgrayhip's own RCCL communicator
+    ranks_met = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        ranks_met = int(t.item())
+
     # N > 1: who issues the halo exchange.  native = libgrayhip's own RCCL communicator, whole step in one C++ call.
     native, exchange, exchange_note = None, "none", ""
     comms_to_close = []
+    rccl_ranks = None
     if world > 1:
         exchange = "torch.distributed P2P (batch_isend_irecv over RCCL)"
         if args.exchange == "native":
@@ -223,16 +444,29 @@ def main() -> int:
                 comms_to_close.append(native)
             if not all_ranks_agree(native is not None):
                 native = None
+            if native is not None:
+                one = torch.ones(1, dtype=torch.int64, device=device)
+                native.allreduce_sum_u64(one, stream.cuda_stream)
+                torch.cuda.synchronize()
+                rccl_ranks = int(one.item())
 
-    # Synthetic frames, resident in HBM before the timed region.  N = 1: one frame.  N > 1: a ring of three frames (a
-    # stream of frames, step k works on frame k % 3), so that the halo rows of a later frame can be exchanged while the
-    # current one is processed -- every step still does one full exchange and one full pass over a 16384-wide shard.
-    NBUF = 1 if world == 1 else 3
-    gen = torch.Generator(device=device)
+    # Synthetic frames, resident in HBM before the timed region: SURVEY.md 8(c) rand(seed), this rank's rows of it.
+    # N = 1: one frame, rand(seed=1).  N > 1: a ring of three frames, rand(seed = 1, 2, 3) (a stream of frames, step k works
+    # on frame k % 3), so that the halo rows of a later frame can be exchanged while the current one is processed.
+    NBUF = 1 if single else 3
+    row_bytes = W * 3
+    aligned8 = (y0 * row_bytes) % 8 == 0 and (rows * row_bytes) % 8 == 0
     runners, rgbs = [], []
     for i in range(NBUF):
-        gen.manual_seed(1234 + rank + 1000 * i)
-        frame = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
+        if aligned8:
+            frame = splitmix_bytes(torch, device, y0 * row_bytes, rows * row_bytes, seed=1 + i).view(rows, W, 3)
+        else:                        # odd geometry given on the command line: any bytes will do for timing
+            gen = torch.Generator(device=device)
+            gen.manual_seed(1234 + rank + 1000 * i)
+            frame = torch.randint(0, 256, (rows, W, 3), dtype=torch.uint8, device=device, generator=gen)
+        if single:
+            rgbs.append(frame)
+            continue
         if fused:
             r = sharding.ShardedFusedGraySobel(geom, backend, device, channels=3, overlap=overlap)
             r.shard.copy_(frame)
@@ -242,247 +476,346 @@ def main() -> int:
             r = sharding.ShardedGraySobel(geom, backend, device, overlap=overlap)
             rgbs.append(frame)
         runners.append(r)
-    runner, rgb = runners[0], rgbs[0]
-    halo_bufs = [r.rgb for r in runners] if fused else [r.luma for r in runners]     # (rows+2)-row buffers, halo rows 0 / rows+1
-    stream = torch.cuda.current_stream()
-    single = world == 1
+    rgb = rgbs[0]
+    halo_bufs = ([r.rgb for r in runners] if fused else [r.luma for r in runners]) if not single else []   # (rows+2)-row buffers
+    KA = known_answers()
+    is_known_frame = aligned8 and W == 16384 and H_total == 16384
+    ka_mode = "FMA" if mode == pkg.MODE_FMA else "IEEE"
 
-    def torch_step(k):            # exchange issued by torch.distributed P2P ops, frame k % NBUF, result in that runner's edge
-        r = runners[k % NBUF]
-        return r.step() if fused else r.step(rgbs[k % NBUF])
+    out = {}
+    check = "skipped"
+    halo_ok = True
 
-    step_impl, edge_of = torch_step, (lambda k: runners[k % NBUF].edge)
-    if native is not None:
-        # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
-        AHEAD = 2
-        edge_native = torch.empty((rows, W), dtype=torch.uint8, device=device)
-        try:
-            if fused:
-                pstep = native.bind_fused_step_pipelined(halo_bufs, edge_native, rows, mode, ahead=AHEAD)
-                native_step = pstep
-            else:
-                pstep = native.bind_sobel_step_pipelined(halo_bufs, edge_native, rows, ahead=AHEAD)
-                grays = [backend.bind_gray_to_plane(rgbs[i], halo_bufs[i][1:rows + 1]) for i in range(NBUF)]
-                for g_ in grays:
-                    g_()          # prologue: luma of every frame of the ring exists before its halo is first requested
+    if single:
+        # ================================ one GPU =========================================================================
+        luma = torch.zeros((rows + 2, W), dtype=torch.uint8, device=device)
+        edge = torch.empty((rows, W), dtype=torch.uint8, device=device)
+        rgb_ptr, edge_ptr, luma_ptr = rgb.data_ptr(), edge.data_ptr(), luma.data_ptr()
+        s_ptr = stream.cuda_stream
+        chk = pkg.abi.check
 
-                def native_step(k):
-                    grays[(k + AHEAD) % NBUF]()      # luma of the frame whose halo is requested in this step
-                    pstep(k)
-            # every frame of the ring through both paths: the C++ path must reproduce torch.distributed bit for bit
-            same = True
-            for k in range(NBUF):
-                torch_step(k)
-            torch.cuda.synchronize()
-            for k in range(2 * NBUF):
-                native_step(k)
-                torch.cuda.synchronize()
-                same = same and bool(torch.equal(edge_native, runners[k % NBUF].edge))
-        except Exception as exc:
-            same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
-        if all_ranks_agree(same or rehearsal_loopback):
-            exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
-                        f"the halo rows of frame k+{AHEAD} travel while frame k is processed")
-            step_impl, edge_of = native_step, (lambda k: edge_native)
-        else:
-            exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
-            native = None
+        def step_fused(k, ev):
+            if ev:
+                ev[0].record(stream)
+            chk(lib.gh_gray_sobel_fused_rows_dev(rgb_ptr, edge_ptr, W, rows, 3, mode, 1, 1, s_ptr), "fused")
+            if ev:
+                ev[-1].record(stream)
 
-    n_ev = 3 if (single and not fused) else 2
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
-    edge = runner.edge
-    step_no = [0]
-
-    def step(ev=None):
-        k = step_no[0]
-        step_no[0] += 1
-        if ev:
-            ev[0].record(stream)
-        if single and fused:
-            runner.step()
-        elif single:
-            api.gray_to_plane(rgb, mode, out=runner.luma[1:rows + 1])
+        def step_split(k, ev):
+            if ev:
+                ev[0].record(stream)
+            chk(lib.gh_gray_rgb8_to_plane_dev(rgb_ptr, luma_ptr + W, rows * W, 3, mode, s_ptr), "gray")
             if ev:
                 ev[1].record(stream)
-            api.sobel_rows(runner.luma, edge, rows, True, True)
-        else:
-            step_impl(k)
-        if ev:
-            ev[-1].record(stream)
+            chk(lib.gh_sobel_u8_rows_dev(luma_ptr + W, edge_ptr, W, rows, 1, 1, s_ptr), "sobel")
+            if ev:
+                ev[-1].record(stream)
 
-    def fence():
+        first, second = (step_fused, step_split) if fused else (step_split, step_fused)
+        n_first, n_second = (2, 3) if fused else (3, 2)
+        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(n_first)] for _ in range(args.steps)]
+        run_in(first)
+        elapsed, host_enqueue = timed(first, args.steps, ev1)
+        step_ms_events = sum(e[0].elapsed_time(e[-1]) for e in ev1) / args.steps
+        timed_kernels, region_of = {}, {}
+
+        def note(events, is_fused, region):
+            if is_fused:
+                timed_kernels["gray_sobel_fused_rgb8"] = sum(e[0].elapsed_time(e[-1]) for e in events) / len(events)
+                region_of["gray_sobel_fused_rgb8"] = region
+            else:
+                timed_kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+                timed_kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+                region_of["gray_rgb8_to_plane"] = region_of["sobel3x3_u8"] = region
+
+        note(ev1, fused, "value")
+        # parity of what was just timed: the WHOLE frame against the compiled reference's SHA-256 (tests/golden/known_answers.json)
+        if not args.no_check:
+            if is_known_frame and KA:
+                want_in, want_edge = KA["frames"]["rand1_16384"]["in"], KA[ka_mode]["rand1_16384"]["edge"]
+                got_in, got_edge = sha256_of(rgb), sha256_of(edge)
+                check = "ok: full-frame SHA-256 of input and edge plane == compiled reference" if (got_in == want_in and got_edge == want_edge) \
+                    else f"MISMATCH (input {'ok' if got_in == want_in else got_in[:16]}, edge {'ok' if got_edge == want_edge else got_edge[:16]})"
+            else:
+                try:
+                    import numpy as np
+                    from oracle import pyoracle as O          # checker only, never the thing measured
+                    r = min(rows, 96)
+                    want = O.sobel(O.gray_to_plane(rgb[0:r + 1].cpu().numpy(), mode))[: r - 1]
+                    got = edge[: r - 1].cpu().numpy()
+                    check = "ok (first rows vs oracle)" if (np.array_equal(got[1:], want[1:]) and not got[0].any()) else "MISMATCH"
+                except Exception as exc:
+                    check = f"unavailable ({type(exc).__name__})"
+            if check.startswith("MISMATCH"):
+                print(f"bench.py: parity check FAILED: {check}", file=sys.stderr)
+                return 3
+
+        # second timed region: the other pipeline, same bracket, same K -- so that RGB -> gray and the plane Sobel (or the fused
+        # kernel) also have in-region HIP-event figures
+        other = None
+        if not args.no_kernel_table:
+            ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(n_second)] for _ in range(args.steps)]
+            run_in(second)
+            el2, _ = timed(second, args.steps, ev2)
+            note(ev2, not fused, "second")
+            other = {"pipeline": "split" if fused else "fused", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                     "Mpixels/s": round(W * H_total * args.steps / el2 / 1e6, 1)}
+            if not args.no_check and is_known_frame and KA:
+                got_edge = sha256_of(edge)
+                if got_edge != KA[ka_mode]["rand1_16384"]["edge"]:
+                    print("bench.py: parity check FAILED in the second timed region", file=sys.stderr)
+                    return 3
+                if fused:            # the second region ran the split pipeline: its luma plane is pinned too
+                    if sha256_of(luma[1:rows + 1]) != KA[ka_mode]["rand1_16384"]["gray"]:
+                        print("bench.py: luma plane differs from the compiled reference", file=sys.stderr)
+                        return 3
+                    check += "; split pipeline: luma and edge planes == compiled reference"
+                else:
+                    check += "; fused pipeline: edge plane == compiled reference"
+
+        # outside the timed regions: the in-place reference-ABI kernel, and the copy ceiling of this GPU
+        def time_kernel(fn, reps=30):
+            for _ in range(150):      # run-in: a change of kernel is followed by the same clock dip as a start from idle
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+            b.synchronize()
+            return a.elapsed_time(b) / reps
+
+        kern_ms = dict(timed_kernels)
+        copy_ceiling = None
+        if not args.no_kernel_table:
+            scratch = rgb.clone()
+            kern_ms["gray_inplace_rgb8"] = time_kernel(lambda: api.gray_inplace(scratch, mode))
+            region_of["gray_inplace_rgb8"] = None
+            nb = rgb.numel()
+            sp, dp = rgb.data_ptr(), scratch.data_ptr()
+            ms = time_kernel(lambda: chk(lib.gh_copy_stream_dev(sp, dp, nb, s_ptr), "copy"))
+            copy_ceiling = 2 * nb / (ms * 1e-3) / 1e9
+            del scratch
+
+        value = W * H_total * args.steps / elapsed / 1e6
+        kern_table = {}
+        for name, ms in kern_ms.items():
+            gbs = ALGO_BYTES_PER_PX[name] * px_rank / (ms * 1e-3) / 1e9
+            kern_table[name] = {"ms": round(ms, 4), "algo_bytes": ALGO_BYTES_PER_PX[name] * px_rank,
+                                "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+                                "frac_of_copy_ceiling": round(gbs / copy_ceiling, 4) if copy_ceiling else None,
+                                "Mpixels/s": round(px_rank / (ms * 1e-3) / 1e6, 1),
+                                "in_timed_region": region_of.get(name) is not None, "timed_region": region_of.get(name)}
+        first_kernels = {k: v for k, v in timed_kernels.items() if region_of[k] == "value"}
+        dom = max(first_kernels, key=first_kernels.get)
+        a = kern_table[dom]["GB/s"]
+        traffic, traffic_src = measured_traffic(dom, px_rank)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"],
+                    "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
+                    "frac_of_copy_ceiling": round(a / copy_ceiling, 4) if copy_ceiling else None}
+        out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
+                    "kernels": kern_table, "ms_per_step_events": round(step_ms_events, 4), "second_timed_region": other,
+                    "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
+                    "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1)})
+        parallelism = "single GPU"
+    else:
+        # ================================ N GPUs, row shards ===============================================================
+        def torch_step(k):            # exchange issued by torch.distributed P2P ops, frame k % NBUF, result in that runner's edge
+            r = runners[k % NBUF]
+            return r.step() if fused else r.step(rgbs[k % NBUF])
+
+        pipelined_impl, edge_of = torch_step, (lambda k: runners[k % NBUF].edge)
+        single_impl, single_edge = (lambda k: torch_step(0)), runners[0].edge
+        if native is not None:
+            # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
+            AHEAD = 2
+            edge_native = torch.empty((rows, W), dtype=torch.uint8, device=device)
+            try:
+                if fused:
+                    pstep = native.bind_fused_step_pipelined(halo_bufs, edge_native, rows, mode, ahead=AHEAD)
+                    native_step = pstep
+                    sstep = native.bind_fused_step(halo_bufs[0], edge_native, rows, mode)
+                    native_single = lambda k: sstep()
+                else:
+                    pstep = native.bind_sobel_step_pipelined(halo_bufs, edge_native, rows, ahead=AHEAD)
+                    grays = [backend.bind_gray_to_plane(rgbs[i], halo_bufs[i][1:rows + 1]) for i in range(NBUF)]
+                    for g_ in grays:
+                        g_()          # prologue: luma of every frame of the ring exists before its halo is first requested
+
+                    def native_step(k):
+                        grays[(k + AHEAD) % NBUF]()      # luma of the frame whose halo is requested in this step
+                        pstep(k)
+                    sstep = native.bind_sobel_step(halo_bufs[0], edge_native, rows)
+
+                    def native_single(k):
+                        grays[0]()
+                        sstep()
+                # every frame of the ring through both paths: the C++ path must reproduce torch.distributed bit for bit
+                same = True
+                for k in range(NBUF):
+                    torch_step(k)
+                torch.cuda.synchronize()
+                for k in range(2 * NBUF):
+                    native_step(k)
+                    torch.cuda.synchronize()
+                    same = same and bool(torch.equal(edge_native, runners[k % NBUF].edge))
+                native_single(0)
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(edge_native, runners[0].edge))
+            except Exception as exc:
+                same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
+            if all_ranks_agree(same or rehearsal_loopback):
+                exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
+                            f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed")
+                pipelined_impl, edge_of = native_step, (lambda k: edge_native)
+                single_impl, single_edge = native_single, edge_native
+            else:
+                exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
+                native = None
+
+        calls = {}
+
+        def with_events(impl, name):
+            calls[name] = 0
+
+            def fn(_k, ev):          # the step number runs on through run-in, warm-up and timed steps: the frame ring never skips
+                k = calls[name]
+                calls[name] = k + 1
+                if ev:
+                    ev[0].record(stream)
+                impl(k)
+                if ev:
+                    ev[1].record(stream)
+            return fn
+
+        def run_form(impl, k_steps, name):
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(k_steps)]
+            fn = with_events(impl, name)
+            run_in(fn)
+            el, host = timed(fn, k_steps, ev)
+            return {"ms_per_step": round(el / k_steps * 1e3, 4), "Mpixels/s": round(W * H_total * k_steps / el / 1e6, 1),
+                    "ms_per_step_events_rank0": round(sum(e[0].elapsed_time(e[1]) for e in ev) / k_steps, 4),
+                    "host_enqueue_us_per_step": round(host * 1e6 / k_steps, 1), "steps": k_steps}, el
+
+        forms = {}
+        # (b) ONE frame, strong-scaled: exchange || interior rows, then the first and last row
+        forms["single_frame"], _ = run_form(single_impl, args.steps, "single_frame")
+        # Sum of the edge plane over all ranks against the compiled reference's known answer (single-frame form, frame rand(seed=1))
+        edge_sum_check = "skipped"
+        if not args.no_check and not rehearsal_loopback:
+            tsum = single_edge.sum(dtype=torch.int64).reshape(1)
+            if rehearsal:
+                tsum = tsum.cpu()
+            dist.all_reduce(tsum)
+            if is_known_frame and KA and args.scaling == "strong" and ka_mode == "IEEE":
+                want = int(KA["IEEE"]["rand1_16384"]["edge_sum"])
+                edge_sum_check = "ok: sum of the sharded edge plane == compiled reference" if int(tsum.item()) == want else \
+                    f"MISMATCH ({int(tsum.item())} != {want})"
+            else:
+                edge_sum_check = f"unpinned geometry (sum {int(tsum.item())})"
+        # (c) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
+        host_shard = torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True)
+        host_shard.copy_(rgbs[0])
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    if args.settle_ms > 0:           # run-in (untimed, before the warm-up steps): let the clocks settle under this very load
-        t_end = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(16):
-                step()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    host_enqueue = time.perf_counter() - t0       # host time to issue the steps (GPU still running)
-    fence()
-    elapsed = time.perf_counter() - t0
+        def e2e_impl(k):
+            rgbs[0].copy_(host_shard, non_blocking=True)
+            single_impl(k)
+        k_e2e = max(1, min(args.steps, 20))
+        forms["end_to_end_h2d"], _ = run_form(e2e_impl, k_e2e, "end_to_end_h2d")
+        # (a) a stream of frames, software-pipelined -- `value`
+        forms["pipelined"], elapsed = run_form(pipelined_impl, args.steps, "pipelined")
+        value = W * H_total * args.steps / elapsed / 1e6
+        step_ms_events = forms["pipelined"]["ms_per_step_events_rank0"]
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
-    px_rank = rows * W
-    step_ms_events = sum(e[0].elapsed_time(e[-1]) for e in events) / args.steps
-    timed_kernels = {}
-    if single and fused:
-        timed_kernels["gray_sobel_fused_rgb8"] = step_ms_events
-    elif single:
-        timed_kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-        timed_kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-
-    # N > 1: every rank's halo rows must hold its neighbours' edge rows (what the last step's exchange delivered)
-    halo_ok = True
-    last = step_no[0] - 1                       # the frame of the last step is the one checked
-    rgb, edge, hbuf = rgbs[last % NBUF], (edge_of(last) if not single else edge), halo_bufs[last % NBUF]
-    if world > 1:
+        # every rank's halo rows must hold its neighbours' edge rows (what the last pipelined step's exchange delivered)
+        last = calls["pipelined"] - 1
+        lrgb, ledge, hbuf = rgbs[last % NBUF], edge_of(last), halo_bufs[last % NBUF]
         firsts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
         lasts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(firsts, rgb[0].contiguous())
-        dist.all_gather(lasts, rgb[rows - 1].contiguous())
+        dist.all_gather(firsts, lrgb[0].contiguous())
+        dist.all_gather(lasts, lrgb[rows - 1].contiguous())
         up_row, down_row = hbuf[0], hbuf[rows + 1]
-        if fused:
-            conv = lambda t: t
-        else:
-            conv = lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W)
+        conv = (lambda t: t) if fused else (lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W))
         if rank > 0:
             halo_ok &= bool(torch.equal(up_row, conv(lasts[rank - 1])))
         if rank < world - 1:
             halo_ok &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
         halo_ok = all_ranks_agree(halo_ok or rehearsal_loopback)
 
-    # parity spot check of what was just timed (checker only; not in the timed region)
-    check = "skipped"
-    if not args.no_check and rank == 0 and not rehearsal_loopback:
-        try:
-            import numpy as np
-            from oracle import pyoracle as O
-            r = min(rows, 96)
-            src = rgb[0:r + 1].cpu().numpy()
-            want = O.sobel(O.gray_to_plane(src, mode))[: r - 1]
-            got = edge[: r - 1].cpu().numpy()
-            good = np.array_equal(got[1:], want[1:]) and not got[0].any()
-            if world > 1 and fused and rows > 40:
-                # the shard's last rows, which depend on the halo row received from rank 1
-                src = hbuf[rows - 30:rows + 2].cpu().numpy()                # buffer rows = shard rows rows-31 .. rows-1 + the halo row
-                want = O.sobel(O.gray_to_plane(src, mode))[1:-1]             # shard rows rows-30 .. rows-1
-                good = good and np.array_equal(edge[rows - 30:rows].cpu().numpy(), want)
-            check = "ok" if good else "MISMATCH"
-        except Exception as exc:  # the checker is optional on the GPU box; a mismatch is never hidden
-            check = f"unavailable ({type(exc).__name__})"
-        if check == "MISMATCH" or not halo_ok:
-            print(f"bench.py: parity spot check FAILED (check={check}, halo rows ok={halo_ok})", file=sys.stderr)
+        if not args.no_check and rank == 0 and not rehearsal_loopback:
+            try:
+                import numpy as np
+                from oracle import pyoracle as O          # checker only
+                r = min(rows, 96)
+                want = O.sobel(O.gray_to_plane(lrgb[0:r + 1].cpu().numpy(), mode))[: r - 1]
+                got = ledge[: r - 1].cpu().numpy()
+                good = np.array_equal(got[1:], want[1:]) and not got[0].any()
+                if fused and rows > 40:
+                    # the shard's last rows, which depend on the halo row received from rank 1
+                    src = hbuf[rows - 30:rows + 2].cpu().numpy()                # buffer rows = shard rows rows-31 .. rows-1 + the halo row
+                    want = O.sobel(O.gray_to_plane(src, mode))[1:-1]             # shard rows rows-30 .. rows-1
+                    good = good and np.array_equal(ledge[rows - 30:rows].cpu().numpy(), want)
+                check = "ok (rank 0: first rows and the rows behind the received halo vs oracle)" if good else "MISMATCH"
+            except Exception as exc:  # the checker is optional on the GPU box; a mismatch is never hidden
+                check = f"unavailable ({type(exc).__name__})"
+        bad = check == "MISMATCH" or not halo_ok or edge_sum_check.startswith("MISMATCH")
+        if bad:
+            print(f"bench.py: parity check FAILED (check={check}, halo rows ok={halo_ok}, edge sum: {edge_sum_check})", file=sys.stderr)
             return 3
 
-    # per-kernel table (outside the timed region): every kernel of the hot path on this rank's shard
-    def time_kernel(fn, reps=30):
-        for _ in range(150):      # run-in: a change of kernel is followed by the same clock dip as a start from idle
-            fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        for _ in range(reps):
-            fn()
-        b.record(stream)
-        b.synchronize()
-        return a.elapsed_time(b) / reps
-
-    kern_ms = dict(timed_kernels)
-    if single and not args.no_kernel_table and rank == 0:
-        luma = torch.empty((rows + 2, W), dtype=torch.uint8, device=device)
-        tmp_edge = torch.empty((rows, W), dtype=torch.uint8, device=device)
-        if "gray_rgb8_to_plane" not in kern_ms:
-            kern_ms["gray_rgb8_to_plane"] = time_kernel(lambda: api.gray_to_plane(rgb, mode, out=luma[1:rows + 1]))
-        else:
-            api.gray_to_plane(rgb, mode, out=luma[1:rows + 1])
-        if "sobel3x3_u8" not in kern_ms:
-            kern_ms["sobel3x3_u8"] = time_kernel(lambda: api.sobel_rows(luma, tmp_edge, rows, True, True))
-        if "gray_sobel_fused_rgb8" not in kern_ms:
-            kern_ms["gray_sobel_fused_rgb8"] = time_kernel(lambda: api.gray_sobel_fused(rgb, mode, out=tmp_edge))
-        scratch = rgb.clone()
-        kern_ms["gray_inplace_rgb8"] = time_kernel(lambda: api.gray_inplace(scratch, mode))
-        del luma, tmp_edge, scratch
+        bpp = 4 if fused else 6
+        a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": ("gray_sobel_fused_rgb8" if fused else "gray_rgb8_to_plane+sobel3x3_u8")
+                    + " (per rank, pipelined step incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None}
+        out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
+                    "step_pipelined_ms": forms["pipelined"]["ms_per_step"], "step_single_frame_ms": forms["single_frame"]["ms_per_step"],
+                    "step_end_to_end_ms": forms["end_to_end_h2d"]["ms_per_step"], "step_forms": forms,
+                    "ms_per_step_events": step_ms_events, "edge_sum_check": edge_sum_check,
+                    "host_enqueue_us_per_step": forms["pipelined"]["host_enqueue_us_per_step"]})
+        halo = "RGB row (the fused kernel recomputes halo luma)" if fused else "luma row"
+        parallelism = (f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv; value = pipelined form "
+                       f"(stream of frames, ring of {NBUF}); single_frame and end_to_end_h2d forms in step_forms")
 
     if rank == 0:
-        total_px = W * H_total * args.steps
-        value = total_px / elapsed / 1e6
-        kern_table = {}
-        for name, ms in kern_ms.items():
-            gbs = ALGO_BYTES_PER_PX[name] * px_rank / (ms * 1e-3) / 1e9
-            kern_table[name] = {"ms": round(ms, 4), "algo_bytes": ALGO_BYTES_PER_PX[name] * px_rank,
-                                "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
-                                "Mpixels/s": round(px_rank / (ms * 1e-3) / 1e6, 1),
-                                "in_timed_region": name in timed_kernels}
-        if timed_kernels:
-            dom = max(timed_kernels, key=timed_kernels.get)
-            a = kern_table[dom]["GB/s"]
-            traffic, traffic_src = measured_traffic(dom, px_rank)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"]}
-        else:
-            # N > 1: the step interleaves kernels with the RCCL exchange; report the step's aggregate traffic rate per rank
-            bpp = 4 if fused else 6
-            a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": ("gray_sobel_fused_rgb8" if fused else "gray_rgb8_to_plane+sobel3x3_u8")
-                        + " (per rank, incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None}
-        halo = "RGB row (the fused kernel recomputes halo luma)" if fused else "luma row"
-        out = {
+        final = {
             "metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel",
-            "value": round(value, 1),
+            "value": out.pop("value"),
             "unit": "Mpixels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": out.pop("ms_per_step"),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H_total} RGB8 frame resident in HBM -> luma -> 3x3 Sobel edge plane "
+                "workload": f"{W}x{H_total} RGB8 frame rand(seed=1) (SURVEY 8c generator) resident in HBM -> luma -> 3x3 Sobel edge plane "
                             f"(BASELINE configs[{2 if world == 1 else 3}]), pipeline={args.pipeline}, mode={args.mode}",
                 "width": W, "height": H_total, "rows_per_gpu": rows,
-                "parallelism": "single GPU" if world == 1 else
-                               f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv"
-                               + (", beside the kernels of an earlier frame of the ring (software-pipelined)" if native is not None else
-                                  ("" if args.no_overlap else ", overlapped with the interior rows")),
+                "parallelism": parallelism,
                 "halo_exchange": exchange + (f" [{exchange_note}]" if exchange_note else ""),
             },
-            "roofline": roofline,
-            "kernels": kern_table,
-            "ms_per_step_events": round(step_ms_events, 4),
-            "parity_spot_check": check,
-            "halo_rows_check": "ok" if halo_ok else "MISMATCH",
-            "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1),
-            "settle_ms": args.settle_ms,
+            "ranks": ranks_met,
+            "rccl_ranks": rccl_ranks,
         }
+        final.update(out)
+        final.update({"parity_check": check, "halo_rows_check": "ok" if halo_ok else "MISMATCH", "settle_ms": args.settle_ms})
         if rehearsal:
-            out["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
+            final["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(W, min(args.cpu_sample_rows, H_total))
+                final["cpu_baseline"] = cpu_baseline(W, H_total, args.cpu_budget_s)
             except Exception as exc:
-                out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "unavailable",
-                                       "sample": f"{type(exc).__name__}: {exc}"}
+                final["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "unavailable",
+                                         "sample": f"{type(exc).__name__}: {exc}"}
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(final) + "\n").encode())
 
     if world > 1:
         torch.cuda.synchronize()

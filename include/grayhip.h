@@ -66,6 +66,11 @@ GH_API int gh_copy_h2d(void *dst_dev, const void *src_host, size_t nbytes, gh_st
 GH_API int gh_copy_d2h(void *dst_host, const void *src_dev, size_t nbytes, gh_stream_t stream);
 GH_API int gh_stream_sync(gh_stream_t stream);
 
+/* measurement aid ("confirm on the box with a copy-kernel ceiling"): linear nontemporal
+ * copy of nbytes (16-byte aligned buffers and size), 1 R + 1 W -- the achievable HBM rate bench.py reports beside
+ * the 8 TB/s spec peak.  Replaces nothing in the reference. */
+GH_API int gh_copy_stream_dev(const void *src, void *dst, size_t nbytes, gh_stream_t stream);
+
 /* ---- device-resident kernels (the measured hot path) ------------------------------------- */
 
 /* RGB8/RGBA8 interleaved -> 1 B/px luma plane.  3 R + 1 W bytes per pixel (channels==3).

@@ -32,6 +32,7 @@ SIGNATURES = {
     "gh_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
     "gh_copy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
     "gh_stream_sync": (C.c_int, [_stream]),
+    "gh_copy_stream_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
     "gh_gray_rgb8_to_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
     "gh_gray_inplace_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, _stream]),
     "gh_gray_inplace_passes_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _stream]),

@@ -171,6 +171,69 @@ __global__ __launch_bounds__(BLOCK) void k_gray_rgba_to_plane(const uint4 *__res
     }
 }
 
+// ---- RGBA8, wave-level forms (monolithic/src/parallel_to_grayscale.c:9-15 with channels == 4) -----------------------
+// A wavefront owns 1024 consecutive pixels = 4 KiB: four FULLY COALESCED nontemporal dwordx4 loads (lane i: vectors
+// i, 64+i, 128+i, 192+i; one RGBA pixel = one dword, so a lane's vector is 4 whole pixels and the INPUT needs no
+// de-interleave).  Plane output: the lane's four luma bytes of load j belong at plane byte 256 j + 4 i, i.e. one dword per
+// lane and load; they go through a private 1 KiB LDS slab (ds_write_b32 x4 lane-linear, ds_read_b128 lane-linear: both
+// conflict-free) so that the wave issues ONE coalesced dwordx4 store instead of four dword stores.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_rgba_to_plane_w(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t nwavegroups)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t slab[BLOCK / 64][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
+    for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
+        const uint4 *p = in + g * 256;
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = stream_core::load_stream(p + 64 * j + lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t px[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            uint32_t y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
+            slab[wave][64 * j + lane] = y[0] | (y[1] << 8) | (y[2] << 16) | (y[3] << 24);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint4 r = reinterpret_cast<const uint4 *>(slab[wave])[lane];
+        __builtin_amdgcn_wave_barrier();
+        stream_core::store_stream(out + g * 64 + lane, r);
+    }
+}
+
+// in place: loads and stores are lane-linear already; one wave per 4 KiB, nontemporal both ways
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgba_w(uint4 *__restrict__ data, size_t nwavegroups, int extra)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * (BLOCK / 64);
+    for (size_t g = (size_t)blockIdx.x * (BLOCK / 64) + wave; g < nwavegroups; g += stride) {
+        uint4 *p = data + g * 256;
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = stream_core::load_stream(p + 64 * j + lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t px[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t y = luma_again<MODE>(gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2)), extra);
+                px[k] = (px[k] & 0xff000000u) | (y * 0x00010101u);
+            }
+            stream_core::store_stream(p + 64 * j + lane, make_uint4(px[0], px[1], px[2], px[3]));
+        }
+    }
+}
+
+// ---- measurement aid: linear nontemporal copy (1 R + 1 W), the "achievable" HBM ceiling of SURVEY.md section 8(d) -------
+__global__ __launch_bounds__(BLOCK) void k_copy_stream(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += stride) stream_core::store_stream(out + i, stream_core::load_stream(in + i));
+}
+
 // ---- in place, reference ABI: R=G=B=luma, alpha untouched --------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_gray_inplace_rgb(uint4 *__restrict__ data, size_t ngroups, int extra)
@@ -342,7 +405,6 @@ int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, in
     size_t done = 0;
     if ((channels == 3 || channels == 4) && gh_aligned16(rgb) && gh_aligned16(gray) && npix >= PX_PER_LANE) {
         const size_t ngroups = npix / PX_PER_LANE;
-        const unsigned grid = grid_for(ngroups);
         auto in = reinterpret_cast<const uint4 *>(rgb);
         auto out = reinterpret_cast<uint4 *>(gray);
         if (channels == 3) {
@@ -359,8 +421,18 @@ int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, in
                 else k_gray_rgb_to_plane<GH_MODE_IEEE><<<1, BLOCK, 0, s>>>(in + nwg * 192, out + nwg * 64, rest);
             }
         } else {
-            if (mode == GH_MODE_FMA) k_gray_rgba_to_plane<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
-            else k_gray_rgba_to_plane<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(in, out, ngroups);
+            const size_t nwg = ngroups / 64;                 // whole wavefront groups of 1024 px (4 KiB in, 1 KiB out)
+            if (nwg) {
+                const unsigned gw = grid_for(nwg * 64);
+                if (mode == GH_MODE_FMA) k_gray_rgba_to_plane_w<GH_MODE_FMA><<<gw, BLOCK, 0, s>>>(in, out, nwg);
+                else k_gray_rgba_to_plane_w<GH_MODE_IEEE><<<gw, BLOCK, 0, s>>>(in, out, nwg);
+                GH_LAUNCH_CHECK();
+            }
+            const size_t rest = ngroups - nwg * 64;
+            if (rest) {
+                if (mode == GH_MODE_FMA) k_gray_rgba_to_plane<GH_MODE_FMA><<<1, BLOCK, 0, s>>>(in + nwg * 256, out + nwg * 64, rest);
+                else k_gray_rgba_to_plane<GH_MODE_IEEE><<<1, BLOCK, 0, s>>>(in + nwg * 256, out + nwg * 64, rest);
+            }
         }
         GH_LAUNCH_CHECK();
         done = ngroups * PX_PER_LANE;
@@ -371,6 +443,18 @@ int gh_gray_rgb8_to_plane_dev(const uint8_t *rgb, uint8_t *gray, size_t npix, in
         else k_gray_to_plane_px<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(rgb, gray, done, npix, channels);
         GH_LAUNCH_CHECK();
     }
+    return GH_OK;
+}
+
+int gh_copy_stream_dev(const void *src, void *dst, size_t nbytes, gh_stream_t stream)
+{
+    if (nbytes == 0) return GH_OK;
+    GH_REQUIRE(src && dst, "null pointer");
+    GH_REQUIRE(gh_aligned16(src) && gh_aligned16(dst) && nbytes % 16 == 0, "16-byte aligned buffers and size only");
+    if (int rc = gh_ensure_init()) return rc;
+    const size_t n16 = nbytes / 16;
+    k_copy_stream<<<grid_for(n16), BLOCK, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst), n16);
+    GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
@@ -408,10 +492,18 @@ int gh_gray_inplace_passes_dev(uint8_t *data, size_t npix, int channels, int mod
             }
             done = ngroups * PX_PER_LANE;
         } else {
-            const size_t nquads = npix / 4;
-            const unsigned grid = grid_for(nquads);
-            if (mode == GH_MODE_FMA) k_gray_inplace_rgba<GH_MODE_FMA><<<grid, BLOCK, 0, s>>>(p, nquads, extra);
-            else k_gray_inplace_rgba<GH_MODE_IEEE><<<grid, BLOCK, 0, s>>>(p, nquads, extra);
+            const size_t nquads = npix / 4, nwg = nquads / 256;   // wavefront groups of 1024 px = 256 dwordx4
+            if (nwg) {
+                const unsigned gw = grid_for(nwg * 64);
+                if (mode == GH_MODE_FMA) k_gray_inplace_rgba_w<GH_MODE_FMA><<<gw, BLOCK, 0, s>>>(p, nwg, extra);
+                else k_gray_inplace_rgba_w<GH_MODE_IEEE><<<gw, BLOCK, 0, s>>>(p, nwg, extra);
+                GH_LAUNCH_CHECK();
+            }
+            const size_t rest = nquads - nwg * 256;
+            if (rest) {
+                if (mode == GH_MODE_FMA) k_gray_inplace_rgba<GH_MODE_FMA><<<1, BLOCK, 0, s>>>(p + nwg * 256, rest, extra);
+                else k_gray_inplace_rgba<GH_MODE_IEEE><<<1, BLOCK, 0, s>>>(p + nwg * 256, rest, extra);
+            }
             done = nquads * 4;
         }
         GH_LAUNCH_CHECK();

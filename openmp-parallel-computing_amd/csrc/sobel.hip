@@ -119,7 +119,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // but the prefetch depth costs LDS (1 KiB per row and wave) instead of registers, so it can be deep: the plane kernel
 // moves only 2 B/px, a wave's row is consumed in ~550 cycles and the register-staged form cannot keep enough bytes
 // in flight at 3 waves per SIMD.  The last strip of a row is shifted left to end at the frame edge (all strips full).
-template <int D, int PROBE = 0, int SP = 2>
+template <int D, int PROBE = 0, int SP = 2, int LP = 1>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        glds_row1k(d, rowb, voff);
+        glds_row1k<LP>(d, rowb, voff);
         if (lane < 2) glds_dword(d + STRIP_PX, rowb, hoff);
     };
 #pragma unroll
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
                     G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
                 G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
                 G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
-                uint4 out = (j & 1) ? rowf2<1, 1, PROBE>(st, G, half2) : rowf2<0, 1, PROBE>(st, G, half2);
+                uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
+                if (PROBE == 2) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
                 if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
                     const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
                     if (x == 0) out.x &= 0xffffff00u;
@@ -379,15 +380,17 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
             if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (pad) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES
-            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);     // timing probe: no sqrt (wrong results)
+            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
+            else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
+            else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);  // probe: default-policy DMA loads
+            else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #endif
-            else if (dma <= 2) k_sobel_dma<2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 3) k_sobel_dma<3><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 4) k_sobel_dma<4><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma <= 6) k_sobel_dma<6><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else k_sobel_dma<8><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 3) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             GH_LAUNCH_CHECK();
             return GH_OK;
         }

@@ -354,17 +354,28 @@ __device__ __forceinline__ void glds_row4k(uint32_t lds_slot, const uint8_t *row
                  : "v"(voff), "s"(rowb), "s"(lds_slot)
                  : "memory");
 }
+template <int LP = 1>
 __device__ __forceinline__ void glds_row1k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_slot)
-                 : "memory");
+    if (LP == 0)              // default cache policy (probe: does the halo row of the neighbouring band survive in L2?)
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rowb), "s"(lds_slot)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rowb), "s"(lds_slot)
+                     : "memory");
 }
 __device__ __forceinline__ void glds_dword(uint32_t lds_dst, const uint8_t *rowb, uint32_t voff)
 {

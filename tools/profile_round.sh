@@ -1,19 +1,23 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel statistics and HBM traffic counters of the contract bench.
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel statistics and counters of the contract bench command.
 #   usage: tools/profile_round.sh <out dir under gpurun_out/>
-# Kernel trace / stats and the PMC passes are separate processes (never combined), one counter per pass.
+# The default bench command times the fused pipeline (its `value`) and, in a second timed region, the split pipeline,
+# so ONE command covers k_fused_dma, k_gray_rgb_to_plane_w and k_sobel_dma.  Kernel trace / stats and the PMC passes are
+# separate processes (never combined); FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), the SQ / GRBM counters in
+# a third.  The program follows `--` directly (no env / bash -c hop).
 set -e -o pipefail
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for pl in fused split; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$pl" -- python3 bench.py --pipeline $pl --no-cpu-baseline > "$OUT/bench_under_rocprof_$pl.json" 2> "$OUT/stats_$pl.err"
-  echo "stats $pl done"
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_$pl" -- python3 bench.py --pipeline $pl --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-table --no-check > "$OUT/pmc_${ctr}_$pl.json" 2> "$OUT/pmc_${ctr}_$pl.err"
-    echo "pmc $ctr $pl done"
-  done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+echo "stats done"
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_$ctr" -- python3 bench.py --steps 40 --warmup 2 --settle-ms 100 --no-cpu-baseline --no-check > "$OUT/pmc_$ctr.json" 2> "$OUT/pmc_$ctr.err"
+  echo "pmc $ctr done"
 done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY GRBM_GUI_ACTIVE \
+  --output-format csv -d "$OUT/pmc_SQ" -- python3 bench.py --steps 40 --warmup 2 --settle-ms 100 --no-cpu-baseline --no-check > "$OUT/pmc_SQ.json" 2> "$OUT/pmc_SQ.err"
+echo "pmc SQ done"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 tools/bench_kernels.py > "$OUT/kernel_table.txt" 2>&1
 echo "profile round complete"
