@@ -63,11 +63,18 @@ bin/grayhipd: $(CSRC)/cli/main_server.cpp $(CLI_COMMON) $(CLI_CORE) $(CSRC)/cli/
 oracle:
 	$(MAKE) -C oracle all
 
+# device assembly of the LDS-DMA kernels with the library's own flags (tests/test_isa_vmcnt.py analyses it)
+isa: build_isa/sobel.s build_isa/fused.s
+build_isa/%.s: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p build_isa
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S $< -o $@ 2>/dev/null || $(HIPCC) $(HIPFLAGS) --cuda-device-only -S $< -o $@
+
 clean:
+	rm -rf build_isa
 	rm -f $(HIP_OBJS) $(LIB) bin/grayscale bin/grayscale_sobel bin/grayhipd
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean
+.PHONY: all lib cli oracle clean isa
 
 # developer micro-benchmark (kernel variants; not shipped)
 ubench: bin/ubench

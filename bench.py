@@ -217,7 +217,7 @@ def cpu_has(*flags) -> bool:
     return False
 
 
-def cpu_baseline(width: int, height: int, budget_s: float) -> dict:
+def cpu_baseline(width: int, height: int, budget_s: float, topo: dict | None = None) -> dict:
     """SURVEY.md section 8(d) matrix: {1 thread, all physical cores} x {service flags `-O3 -fopenmp`
     (microservices/grayscale/c/Makefile:2), monolithic flags `-O3 -ffast-math -funroll-loops -fopenmp`
     (monolithic/Makefile:2; built for x86-64-v3 instead of -march=native so that the file runs on another host)},
@@ -233,7 +233,7 @@ def cpu_baseline(width: int, height: int, budget_s: float) -> dict:
     from oracle import pyoracle as O
 
     t_end = time.time() + budget_s
-    topo = host_topology()
+    topo = topo or host_topology()
     nthreads_all = topo["physical"]
     if topo["cgroup_cpus"]:
         nthreads_all = max(1, min(nthreads_all, int(topo["cgroup_cpus"])))
@@ -334,8 +334,12 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    topo = None
     if world == 1:
-        # the CPU baseline's thread placement must be in the environment before ANY OpenMP runtime is loaded (torch brings one)
+        # the CPU baseline's thread placement must be in the environment before ANY OpenMP runtime is loaded (torch brings one);
+        # the host topology is read first: once OMP_PROC_BIND is in force the main thread is bound to ONE core and
+        # sched_getaffinity() would report just that core
+        topo = host_topology()
         os.environ.setdefault("OMP_PLACES", "cores")
         os.environ.setdefault("OMP_PROC_BIND", "close")
 
@@ -410,11 +414,16 @@ def main() -> int:
         if args.settle_ms > 0:       # run-in (untimed, before the warm-up steps): let the clocks settle under this very load
             t_end = time.perf_counter() + args.settle_ms * 1e-3
             k = 0
-            while time.perf_counter() < t_end:
+            while True:
                 for _ in range(16):
                     step_fn(k, None)
                     k += 1
                 torch.cuda.synchronize()
+                done = time.perf_counter() >= t_end
+                if world > 1:        # every step is an exchange with the neighbours: all ranks must run the SAME number of steps
+                    done = all_ranks_agree(done)
+                if done:
+                    break
         for k in range(args.warmup):
             step_fn(k, None)
 
@@ -810,7 +819,7 @@ def main() -> int:
             final["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                final["cpu_baseline"] = cpu_baseline(W, H_total, args.cpu_budget_s)
+                final["cpu_baseline"] = cpu_baseline(W, H_total, args.cpu_budget_s, topo)
             except Exception as exc:
                 final["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "unavailable",
                                          "sample": f"{type(exc).__name__}: {exc}"}

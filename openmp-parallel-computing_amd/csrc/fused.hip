@@ -16,6 +16,8 @@
 #include "sobel_tile.h"
 #include "stream_core.h"
 
+#include <type_traits>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -323,52 +325,69 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * CH);
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        if (CH == 3) glds_row3k<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, rowb, voff); else glds_row4k(dst, rowb, voff);
-        if (lane < 2) glds_dword(dst + STRIP_PX * CH, rowb, hoff);
+        // always exactly NLD vector-memory instructions, one statement
+        if (CH == 3) glds_row3k_halo<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
+        else glds_row4k_halo(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
     };
     // nrows >= 3 > D - 1 for D <= 3; for deeper rings the prologue may run past a very short band: clamp_row keeps it readable
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) issue_row(i, i);
 
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-        // steady state: every one of the last D-1 iterations also issued its output store, so D-1 more operations are
-        // younger than row i's loads (before that, and always safe, only the loads are counted)
-        const bool steady = ch >= 2;
-#pragma unroll
-        for (int j = 0; j < CHK; ++j) {
-            const int i = ch * CHK + j;
-            if (i < nrows) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
-                if (i + D - 1 < nrows) {
-                    issue_row(i + D - 1, (j + D - 1) % D);
-                    if (steady) wait_vm<(NLD + 1) * (D - 1)>(); else wait_vm<NLD * (D - 1)>();
-                } else {
-                    wait_vm<0>();
-                }
-                const uint8_t *slotp = &ring[wave][j % D][0];
-                const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 16 * CH * lane);
-                uint32_t wv[4 * CH];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
-                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
-                const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : hh.y;
-                uint4 out;
-                if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
-                else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
-                if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
-                    const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
-                    if (x == 0) out.x &= 0xffffff00u;
-                    if (x + 15 == w - 1) out.w &= 0x00ffffffu;
-                    if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                    if ((SP % 100) >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
-                        store_strip_p<(SP % 100) % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
-                    else
-                        store_strip_p<(SP % 100) % 10>(edge + (size_t)y * w + xw, lane, out);
-                }
-            }
+    // One row step in three statically different forms (see k_sobel_dma in sobel.hip and tests/test_isa_vmcnt.py):
+    //   KIND 0 generic (rows may be missing, the first two rows produce no output; only the NLD DMA instructions of each of the
+    //   D-1 younger rows are counted), 1 transition (every row exists, issues and stores; same conservative count), 2 steady
+    //   (as 1, and the D-1 previous steps are statically known to have stored: exact count (NLD + 1) (D-1)).
+    auto row_step = [&](auto kind_c, int ch, int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int i = ch * CHK + j;
+        if (KIND == 0 && i >= nrows) return true;                    // past the band: so is every later step -- the wave is done
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
+        if (KIND != 0 || i + D - 1 < nrows) {
+            issue_row(i + D - 1, (j + D - 1) % D);
+            if (KIND == 2) wait_vm<(NLD + 1) * (D - 1)>(j % D); else wait_vm<NLD * (D - 1)>(j % D);
+        } else {
+            wait_vm<0>(j % D);
         }
+        const uint8_t *slotp = &ring[wave][j % D][0];
+        const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 16 * CH * lane);
+        uint32_t wv[4 * CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
+        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
+        const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : hh.y;
+        uint4 out;
+        if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
+        else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
+        if (KIND != 0 || i >= 2) {                                  // y = y0 + i - 2 < rows by construction of nrows
+            const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
+            if (x == 0) out.x &= 0xffffff00u;
+            if (x + 15 == w - 1) out.w &= 0x00ffffffu;
+            if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+            if ((SP % 100) >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
+                store_strip_p<(SP % 100) % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
+            else
+                store_strip_p<(SP % 100) % 10>(edge + (size_t)y * w + xw, lane, out);
+        }
+        return false;
+    };
+    auto chunk = [&](auto kind_c, int ch) {          // true: the band is finished
+#pragma unroll
+        for (int j = 0; j < CHK; ++j)
+            if (row_step(kind_c, ch, j)) return true;
+        return false;
+    };
+    // chunks 0 .. n_full-1 hold only rows that exist and still issue a row: (ch + 1) * CHK - 1 + D - 1 < nrows
+    const int n_full = (nrows - D + 1) / CHK;
+    if (chunk(std::integral_constant<int, 0>{}, 0)) return;
+    int ch = 1;
+    if (n_full >= 2) {
+        chunk(std::integral_constant<int, 1>{}, 1);              // rows CHK .. 2 CHK - 1: all of them store (CHK >= 2)
+#pragma unroll 1
+        for (ch = 2; ch < n_full; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
     }
+#pragma unroll 1
+    for (; ch < nch; ++ch)
+        if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
 template <int MODE, int CH>

@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -167,53 +168,72 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        glds_row1k<LP>(d, rowb, voff);
-        if (lane < 2) glds_dword(d + STRIP_PX, rowb, hoff);
+        glds_row1k_halo<LP>(d, d + STRIP_PX, rowb, voff, hoff, slot);      // always exactly 2 vector-memory instructions
     };
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) issue_row(i, i);
 
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-        const bool steady = ch >= 2;      // every one of the last D-1 iterations also issued its output store (see k_fused_dma)
-#pragma unroll
-        for (int j = 0; j < CHK; ++j) {
-            const int i = ch * CHK + j;
-            if (i < nrows) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
-                if (i + D - 1 < nrows) {
-                    issue_row(i + D - 1, (j + D - 1) % D);
-                    if (steady) wait_vm<3 * (D - 1)>(); else wait_vm<2 * (D - 1)>();
-                } else {
-                    wait_vm<0>();
-                }
-                const uint8_t *slotp = &ring[wave][j % D][0];
-                const uint4 q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
-                const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
-                uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-                uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
-                if (lane == 0) ql = hh.x;
-                if (lane == 63) qr = hh.y;
-                // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
-                const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
-                f32x2 G[10];
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
-                G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
-                G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
-                uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
-                if (PROBE == 2) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
-                if (i >= 2) {                                               // y = y0 + i - 2 < rows by construction of nrows
-                    const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
-                    if (x == 0) out.x &= 0xffffff00u;
-                    if (x + 15 == w - 1) out.w &= 0x00ffffffu;
-                    if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
-                    store_strip_p<SP>(dst + (size_t)y * w + xw, lane, out);
-                }
-            }
+    // One row step, in three statically different forms (so that the generated code can be CHECKED: tests/test_isa_vmcnt.py):
+    //   KIND 0  generic: rows may be missing at the end of the band, the first two rows produce no output.  Only the DMA
+    //           instructions of the D-1 younger rows are counted (2 each); stores in between make the wait conservative.
+    //   KIND 1  transition: every row of the chunk exists, issues a row and stores one; same conservative count.
+    //   KIND 2  steady: as 1, and the D-1 previous steps are statically known to have stored (they ran as KIND 1 or 2),
+    //           so D-1 more operations are younger than row i's DMA: exact count 3 (D-1).
+    auto row_step = [&](auto kind_c, int ch, int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int i = ch * CHK + j;
+        if (KIND == 0 && i >= nrows) return true;                    // past the band: so is every later step -- the wave is done
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
+        if (KIND != 0 || i + D - 1 < nrows) {
+            issue_row(i + D - 1, (j + D - 1) % D);
+            if (KIND == 2) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
+        } else {
+            wait_vm<0>(j % D);
         }
+        const uint8_t *slotp = &ring[wave][j % D][0];
+        const uint4 q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
+        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
+        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+        if (lane == 0) ql = hh.x;
+        if (lane == 63) qr = hh.y;
+        // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
+        const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
+        f32x2 G[10];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+        G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
+        G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
+        uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
+        if (PROBE == 2) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
+        if (KIND != 0 || i >= 2) {                                  // y = y0 + i - 2 < rows by construction of nrows
+            const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
+            if (x == 0) out.x &= 0xffffff00u;
+            if (x + 15 == w - 1) out.w &= 0x00ffffffu;
+            if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+            store_strip_p<SP>(dst + (size_t)y * w + xw, lane, out);
+        }
+        return false;
+    };
+    auto chunk = [&](auto kind_c, int ch) {          // true: the band is finished
+#pragma unroll
+        for (int j = 0; j < CHK; ++j)
+            if (row_step(kind_c, ch, j)) return true;
+        return false;
+    };
+    // chunks 0 .. n_full-1 hold only rows that exist and still issue a row: (ch + 1) * CHK - 1 + D - 1 < nrows
+    const int n_full = (nrows - D + 1) / CHK;
+    if (chunk(std::integral_constant<int, 0>{}, 0)) return;
+    int ch = 1;
+    if (n_full >= 2) {
+        chunk(std::integral_constant<int, 1>{}, 1);              // rows CHK .. 2 CHK - 1: all of them store (CHK >= 2)
+#pragma unroll 1
+        for (ch = 2; ch < n_full; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
     }
+#pragma unroll 1
+    for (; ch < nch; ++ch)
+        if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
 using stream_core::row_readable;

@@ -316,79 +316,60 @@ __device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int
 // ---- LDS-DMA (global_load_lds_*) helpers of the ring kernels (fused.hip k_fused_dma, sobel.hip k_sobel_dma) -------------
 // hipcc does not count asm memory operations: the kernels place their own s_waitcnt vmcnt(N) (wait_vm).  M0 carries the
 // wave-uniform LDS destination; each lane's data lands at M0 + instruction offset + lane * size.
-// LP: cache policy of the DMA loads (0 default, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt); nt measured best, as for register loads
-#define GH_GLDS3(POL)                                                                                 \
-    asm volatile("s_mov_b32 %0, m0\n\t"                                                              \
-                 "s_mov_b32 m0, %3\n\t"                                                              \
-                 "s_nop 0\n\t"                                                                       \
-                 "global_load_lds_dwordx4 %1, %2" POL "\n\t"                                         \
-                 "global_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t"                             \
-                 "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t"                             \
-                 "s_mov_b32 m0, %0"                                                                   \
-                 : "=&s"(keep)                                                                        \
-                 : "v"(voff), "s"(rowb), "s"(lds_slot)                                                \
-                 : "memory")
+// LP: cache policy of the DMA loads (0 default, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt); nt measured best, as for register loads.
+// `slot` (a constant once the row loop is unrolled) is the ring slot the row goes to.  It is printed into the assembly as a
+// comment -- "; gh_dma slot=S" on every DMA instruction, "; gh_wait slot=S" on the wait that precedes the reads of slot S --
+// so that tests/test_isa_vmcnt.py can check ON THE GENERATED CODE that on every path at least N vector-memory instructions
+// are issued between the last DMA into slot S and a `vmcnt(N)` wait for it (vmcnt retires in order: with fewer than N younger
+// operations the wait would return before the row has landed -- silent, timing-dependent corruption).
+// One ring row = ONE asm statement: the wave's 1 KiB pieces (all 64 lanes) followed by the halo dword (EXEC narrowed to
+// lanes 0 and 1 inside the statement, destination right behind the pieces).  A statement is never split or reordered
+// against other volatile asm, so a row is always exactly `pieces + 1` vector-memory instructions in program order -- the
+// quantity the waits are counted in.  (Every lane is active where rows are issued: the strip kernels branch wave-uniformly.)
+#define GH_GLDS_HEAD  "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+#define GH_GLDS_HALO  "s_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, 3\n\t"        \
+                      "global_load_lds_dword %6, %3 ; gh_dma slot=%7\n\t"                         \
+                      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+#define GH_GLDS_OPS   : "=&s"(keep), "=&s"(keepx)                                                    \
+                      : "v"(voff), "s"(rowb), "s"(lds_slot), "s"(lds_halo), "v"(hoff), "i"(slot)    \
+                      : "memory"
+#define GH_PIECE(OFF, POL) "global_load_lds_dwordx4 %2, %3" OFF POL " ; gh_dma slot=%7\n\t"
+// 3 KiB row (RGB8 strip): LP as above
 template <int LP = 1>
-__device__ __forceinline__ void glds_row3k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+__device__ __forceinline__ void glds_row3k_halo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
 {
     uint32_t keep;
-    if (LP == 0) GH_GLDS3("");
-    else if (LP == 2) GH_GLDS3(" sc1");
-    else if (LP == 3) GH_GLDS3(" sc0 sc1");
-    else if (LP == 4) GH_GLDS3(" sc1 nt");
-    else GH_GLDS3(" nt");
+    uint64_t keepx;
+#define GH_ROW3(POL) asm volatile(GH_GLDS_HEAD GH_PIECE("", POL) GH_PIECE(" offset:1024", POL) GH_PIECE(" offset:2048", POL) GH_GLDS_HALO GH_GLDS_OPS)
+    if (LP == 0) GH_ROW3("");
+    else if (LP == 2) GH_ROW3(" sc1");
+    else if (LP == 3) GH_ROW3(" sc0 sc1");
+    else if (LP == 4) GH_ROW3(" sc1 nt");
+    else GH_ROW3(" nt");
+#undef GH_ROW3
 }
-#undef GH_GLDS3
-__device__ __forceinline__ void glds_row4k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+// 4 KiB row (RGBA8 strip)
+__device__ __forceinline__ void glds_row4k_halo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_slot)
-                 : "memory");
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_PIECE(" offset:1024", " nt") GH_PIECE(" offset:2048", " nt") GH_PIECE(" offset:3072", " nt")
+                 GH_GLDS_HALO GH_GLDS_OPS);
 }
+// 1 KiB row (u8 plane strip)
 template <int LP = 1>
-__device__ __forceinline__ void glds_row1k(uint32_t lds_slot, const uint8_t *rowb, uint32_t voff)
+__device__ __forceinline__ void glds_row1k_halo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
 {
     uint32_t keep;
-    if (LP == 0)              // default cache policy (probe: does the halo row of the neighbouring band survive in L2?)
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %3\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(rowb), "s"(lds_slot)
-                     : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %3\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2 nt\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(rowb), "s"(lds_slot)
-                     : "memory");
+    uint64_t keepx;
+    if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_GLDS_HALO GH_GLDS_OPS);     // default policy: probe only
+    else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_HALO GH_GLDS_OPS);
 }
-__device__ __forceinline__ void glds_dword(uint32_t lds_dst, const uint8_t *rowb, uint32_t voff)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rowb), "s"(lds_dst)
-                 : "memory");
-}
+#undef GH_PIECE
+#undef GH_GLDS_OPS
+#undef GH_GLDS_HALO
+#undef GH_GLDS_HEAD
+
 // Band plan of a strip kernel launch: level l has n[l] bands of R[l] rows starting at row y[l]; the last level runs to the
 // end of the frame.  Workgroups are dispatched in blockIdx order, so the short bands of the last levels are the ones still
 // running when the grid drains.
@@ -483,10 +464,12 @@ inline int sanitize_order(int order, int bands, int groups_x)
     return A * 1000 + S * 100 + C * 10 + M;
 }
 
+// wait until at most N vector-memory operations of this wave are outstanding; `slot` = the ring slot whose row the
+// following LDS reads consume (see the gh_dma / gh_wait comment markers above)
 template <int N>
-__device__ __forceinline__ void wait_vm()
+__device__ __forceinline__ void wait_vm(int slot)
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) ; gh_wait slot=%1" ::"n"(N), "i"(slot) : "memory");
 }
 
 // wave-uniform 64-bit pointer / 32-bit value into SGPRs (inline asm "s" operands inside divergent code need it spelled out)

@@ -94,7 +94,7 @@ def test_plain_command_runs_two_ranks_in_rehearsal():
     env = dict(os.environ, GH_BENCH_REHEARSAL="1")
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--width", "4096", "--height", "2048", "--steps", "3",
-                        "--warmup", "1", "--settle-ms", "0"], capture_output=True, text=True, env=env, timeout=600)
+                        "--warmup", "1", "--settle-ms", "30"], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout

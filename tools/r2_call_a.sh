@@ -6,8 +6,8 @@ mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-GH_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 20 --warmup 2 > $O/reh2.json 2> $O/reh2.err; echo "reh2 rc=$?"
-GH_BENCH_REHEARSAL=loopback python3 bench.py --gpus 2 --steps 20 --warmup 2 > $O/reh2_lb.json 2> $O/reh2_lb.err; echo "reh2_lb rc=$?"
+GH_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 2 --steps 20 --warmup 2 > $O/reh2.json 2> $O/reh2.err; echo "reh2 rc=$?"
+GH_BENCH_REHEARSAL=loopback timeout -k 10 300 python3 bench.py --gpus 2 --steps 20 --warmup 2 > $O/reh2_lb.json 2> $O/reh2_lb.err; echo "reh2_lb rc=$?"
 export GRAYHIP_LIB=$PWD/build_probes/libgrayhip_probes.so
 # plane Sobel: small bands + XCD-major order (each XCD streams its own slab of the frame), default and nt DMA policy
 python3 tools/ab_fused.py --op sobel --rounds 5 \
