@@ -316,6 +316,11 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     //              lane 1 -> the 4 bytes after the strip's last byte (pixel xw+1024 = its bytes 0..2); clamped when outside
     uint32_t hoff = lane == 0 ? (uint32_t)xw * CH - 4u : (uint32_t)(xw + STRIP_PX) * CH;   // RGBA: the left dword IS pixel xw-1
     if ((lane == 0 && xw == 0) || (lane != 0 && xw + STRIP_PX >= w)) hoff = 0;
+    // widths that are not multiples of 16 (RGB8): when the right halo pixel is the LAST pixel of the row, the dword behind it
+    // would reach one byte past the row; it is fetched one byte earlier instead and shifted back after the read
+    const int over = (xw + STRIP_PX < w) ? max(0, (xw + STRIP_PX) * CH + 4 - w * CH) : 0;   // wave-uniform: 0 or 1 (RGB8), 0 (RGBA8)
+    if (lane != 0) hoff -= (uint32_t)over;
+    const uint32_t rsh = 8u * (uint32_t)over;
     const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
 
     StateF2 st;
@@ -354,7 +359,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
 #pragma unroll
         for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
         const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
-        const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : hh.y;
+        const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : (hh.y >> rsh);
         uint4 out;
         if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
         else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
@@ -459,7 +464,11 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     };
     // (unaligned strips need ws >= 1024: then every strip is full -- the last one is shifted left -- and the pixel right of
     //  column ws - 1 arrives through lane 63's halo load; a ragged last strip would need column ws from beyond its loads)
-    if (!aligned && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
+    // The LDS-DMA kernel takes any width >= 1024 and any base alignment (see sobel.hip: DMA pieces need no alignment on the
+    // global side, every strip is full); GH_FUSED_DMA_UNALIGNED=0 sends unaligned frames to the register-staged strips + tail.
+    const int dma_knob = GH_TUNE_INT("GH_FUSED_DMA", -1);      // ring depth D (0 = register-staged kernel, -1 = auto)
+    const bool dma_ok = dma_knob != 0 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 1));
+    if (!aligned && !dma_ok && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
         launch_px_cols(0);
         GH_LAUNCH_CHECK();
         return GH_OK;
@@ -469,7 +478,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     if (!use_tile) {
         const int variant = GH_TUNE_INT("GH_FUSED_VARIANT", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = (ws + span - 1) / span;
+        const int groups_x = ((dma_ok ? width : ws) + span - 1) / span;
         const unsigned b = stream_core::BLOCK;
 #define GH_FUSED_LAUNCH(R_, C_, RL_)                                                                                         \
         do {                                                                                                              \
@@ -491,8 +500,8 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
         //    faster than the plain band-major order on every frame shape and shard size tried (16384^2: 72.9 % vs 72.1 %);
         //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
         //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
-        int dma = GH_TUNE_INT("GH_FUSED_DMA", -1);         // ring depth D (0 = register-staged kernel, -1 = auto)
-        if (dma != 0 && aligned && width >= stream_core::STRIP_PX) {
+        int dma = dma_knob;
+        if (dma_ok) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);

@@ -159,6 +159,11 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     //              lane 1 -> the 4 bytes after the strip's last byte (pixel xw+1024 = its byte 0); clamped when outside
     uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + STRIP_PX);
     if ((lane == 0 && xw == 0) || (lane != 0 && xw + STRIP_PX >= w)) hoff = 0;
+    // widths that are not multiples of 16: the right halo pixel may be within 3 bytes of the end of the row; the dword is then
+    // fetched `over` bytes earlier (it never reaches past the row, hence never past the plane) and shifted back after the read
+    const int over = xw + STRIP_PX < w ? max(0, xw + STRIP_PX + 4 - w) : 0;             // wave-uniform, 0 for aligned frames
+    if (lane != 0) hoff -= (uint32_t)over;
+    const uint32_t rsh = 8u * (uint32_t)over;
     const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
 
     StateF2 st;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
         uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
         if (lane == 0) ql = hh.x;
-        if (lane == 63) qr = hh.y;
+        if (lane == 63) qr = hh.y >> rsh;
         // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
         const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
         f32x2 G[10];
@@ -362,19 +367,23 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     // the last width % 16 columns.  (All per-pixel: 0.69 ms on 16370 x 16384; this way: 0.125 ms.)
     const int ws = width & ~15;
     // (small unaligned frames stay on the single per-pixel launch: 1921 x 1081 takes 7 us that way, 11 us as strips + tail)
+    static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
+    const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
+    // The LDS-DMA kernel takes ANY width >= 1024 and any base alignment: a DMA piece is 64 lanes x 16 B from consecutive global
+    // addresses that need no alignment (only the LDS side is lane-linear), every strip is full (the last one is shifted left
+    // to end at the frame edge), so a row pitch that is not a multiple of 16 changes nothing but the address arithmetic --
+    // no per-pixel column tail.  GH_SOBEL_DMA_UNALIGNED=0 sends such frames back to the register-staged strips + tail.
+    const bool use_dma = !use_tile && dma && core == 1 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 1));
     const bool strips = !use_tile && ws >= 16 &&
-                        (aligned || (GH_TUNE_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_TUNE_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
+                        (aligned || use_dma || (GH_TUNE_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_TUNE_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
     if (strips) {
-        static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
         const int r_env = GH_TUNE_INT("GH_SOBEL_R", 0);   // tuning knob
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = (ws + span - 1) / span;
+        const int groups_x = ((use_dma ? width : ws) + span - 1) / span;
         // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 64)
         // but a shard must still give every CU a few workgroups.  Power-of-two heights only: band starts aligned to
         // 2^k rows measured 10-15 % faster than 30 / 34 / 48 / 60-row bands in the no-compute strip-copy probe.
         int R = r_env;
-        const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
-        const bool use_dma = dma && core == 1 && aligned && width >= stream_core::STRIP_PX;
         // the LDS-DMA kernel takes any band height (tuning knob); the register-staged one is instantiated for 16 / 32 / 64
         if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);

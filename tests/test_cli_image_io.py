@@ -61,6 +61,70 @@ def test_decoder_equals_reference_stb(tmp_path, name):
     assert mine.shape == theirs.shape and np.array_equal(mine, theirs)
 
 
+def _photo_like(w, h, seed):
+    """Smooth gradients + edges + noise: every coefficient band and both chroma planes carry something."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) * 7) % 256], axis=-1).astype(np.int32)
+    img[h // 3: 2 * h // 3, w // 4: w // 2] = [250, 20, 30]
+    img += rng.randint(-25, 26, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+JPEG_VARIANTS = [
+    # (name, size, PIL mode, save options)
+    ("base444", (67, 45), "RGB", dict(quality=90, subsampling=0)),
+    ("base422", (67, 45), "RGB", dict(quality=85, subsampling=1)),
+    ("base420", (67, 45), "RGB", dict(quality=75, subsampling=2)),
+    ("base420_tiny", (1, 1), "RGB", dict(quality=75, subsampling=2)),
+    ("base420_narrow", (3, 50), "RGB", dict(quality=75, subsampling=2)),
+    ("base420_16", (16, 16), "RGB", dict(quality=60, subsampling=2)),
+    ("base420_17", (17, 33), "RGB", dict(quality=60, subsampling=2)),
+    ("optimised", (130, 71), "RGB", dict(quality=92, subsampling=2, optimize=True)),
+    ("q100", (64, 64), "RGB", dict(quality=100, subsampling=0)),
+    ("q5", (120, 90), "RGB", dict(quality=5, subsampling=2)),
+    ("prog444", (67, 45), "RGB", dict(quality=90, subsampling=0, progressive=True)),
+    ("prog422", (131, 77), "RGB", dict(quality=80, subsampling=1, progressive=True)),
+    ("prog420", (131, 77), "RGB", dict(quality=70, subsampling=2, progressive=True)),
+    ("prog420_q30", (200, 120), "RGB", dict(quality=30, subsampling=2, progressive=True, optimize=True)),
+    ("grey", (75, 51), "L", dict(quality=85)),
+    ("grey_prog", (75, 51), "L", dict(quality=85, progressive=True)),
+    ("restart_blocks", (150, 70), "RGB", dict(quality=80, subsampling=2, restart_marker_blocks=3)),
+    ("restart_rows", (150, 70), "RGB", dict(quality=80, subsampling=0, restart_marker_rows=1)),
+    ("restart_prog", (150, 70), "RGB", dict(quality=80, subsampling=2, progressive=True, restart_marker_blocks=5)),
+    ("cmyk", (60, 40), "CMYK", dict(quality=85)),
+    ("big_prog", (517, 389), "RGB", dict(quality=88, subsampling=2, progressive=True)),
+]
+
+
+@pytest.mark.skipif(not os.access(STB, os.X_OK), reason="the reference's decoder is compiled only where /root/reference exists")
+@pytest.mark.parametrize("name,size,mode,opts", JPEG_VARIANTS, ids=[v[0] for v in JPEG_VARIANTS])
+def test_generated_jpegs_decode_like_the_reference(tmp_path, name, size, mode, opts):
+    """Streams written here by libjpeg (through PIL) in the shapes a JPEG can take -- baseline / progressive, 4:4:4 / 4:2:2 /
+    4:2:0, greyscale, restart intervals, optimised Huffman tables, Adobe CMYK -- must come out of this repo's decoder exactly as
+    out of the reference's (stb_image v2.30 compiled in place): same size, same channel count, same bytes."""
+    w, h = size
+    rgb = _photo_like(w, h, seed=len(name) * 131 + w)
+    if mode == "L":
+        img = Image.fromarray(rgb[..., 0])
+    elif mode == "CMYK":
+        img = Image.fromarray(rgb).convert("CMYK")
+    else:
+        img = Image.fromarray(rgb)
+    path = tmp_path / f"{name}.jpg"
+    try:
+        img.save(path, "JPEG", **opts)
+    except TypeError:
+        pytest.skip("this Pillow does not know one of the save options")
+    mine = decode(path, tmp_path)
+    raw = tmp_path / "s.raw"
+    out = subprocess.run([STB, str(path), str(raw)], check=True, capture_output=True, text=True).stdout.split()
+    sw, sh, sc = map(int, out)
+    theirs = np.fromfile(raw, dtype=np.uint8).reshape(sh, sw, sc)
+    assert mine.shape == theirs.shape, (mine.shape, theirs.shape)
+    assert np.array_equal(mine, theirs), f"{name}: {np.count_nonzero(mine != theirs)} bytes differ"
+
+
 @pytest.mark.parametrize("w,h,c", [(1, 1, 1), (7, 3, 2), (53, 37, 3), (64, 64, 4), (300, 2, 3), (2, 300, 1)])
 def test_png_encode_roundtrip(tmp_path, w, h, c):
     rng = np.random.RandomState(w * 100 + h + c)

@@ -554,10 +554,14 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
         native_comm.set_loopback(False)
 
 
-@pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3)])
-def test_fused_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, c, monkeypatch):
-    """The fused C entry point takes any width: unaligned strips + per-pixel column tail (forced on for small frames here),
-    the per-pixel kernel alone, and unaligned buffer bases; whole frames and bands with real RGB halo rows."""
+@pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3),
+                                   (1025, 5, 3), (1025, 67, 4), (1026, 130, 3), (3073, 65, 3), (2037, 90, 3), (16370, 24, 3)])
+@pytest.mark.parametrize("dma_unaligned", ["1", "0"])
+def test_fused_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, c, dma_unaligned, monkeypatch):
+    """The fused C entry point takes any width.  Widths >= 1024: the LDS-DMA ring kernel itself (DMA pieces need no alignment on
+    the global side; GH_FUSED_DMA_UNALIGNED=0: register-staged unaligned strips + per-pixel column tail instead); narrower
+    frames: strips + tail or the per-pixel kernel alone; unaligned buffer bases; whole frames and bands with real RGB halo rows."""
+    monkeypatch.setenv("GH_FUSED_DMA_UNALIGNED", dma_unaligned)
     img = oracle.frame_rand(w, h, c, seed=w * 3 + h)
     d = dev(torch_mod, img)
     for min_px in ("1", str(1 << 30)):
@@ -622,8 +626,10 @@ def test_random_geometry_sweep(pkg, oracle, torch_mod):
     shifted last strip, one- and two-row frames) for the plane Sobel, the fused RGB8 / RGBA8 kernels and their band forms."""
     rnd = np.random.RandomState(20261004)
     shapes = [(1024, 1), (1024, 64), (1024, 65), (2048, 66), (1040, 63), (3072, 17), (16, 1), (32, 2), (1008, 40)]
-    for _ in range(int(os.environ.get("GH_SWEEP", "24"))):
+    for k in range(int(os.environ.get("GH_SWEEP", "24"))):
         w = 16 * int(rnd.randint(1, 330))
+        if k % 3 == 2:
+            w = int(rnd.randint(1024, 5300))          # any width through the LDS-DMA ring kernels
         h = int(rnd.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 66, 67, 127, 129, 130, 200]))
         shapes.append((w, h))
     for (w, h) in shapes:
@@ -694,10 +700,15 @@ def test_many_passes(pkg, oracle, torch_mod, w, h, c):
         assert np.array_equal(host, want_img), ("pipeline", passes)
 
 
-@pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2)])
-def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, monkeypatch):
-    """Frame widths that are not a multiple of 16 (rows start at unaligned bytes): the strip kernel covers the first
-    w & ~15 columns with unaligned vector accesses, a per-pixel kernel the rest; forced on for small frames here."""
+@pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2), (1025, 5), (1026, 67), (1027, 130), (1028, 3),
+                                 (2049, 70), (3073, 65), (2037, 90), (16370, 24)])
+@pytest.mark.parametrize("dma_unaligned", ["1", "0"])
+def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, dma_unaligned, monkeypatch):
+    """Frame widths that are not a multiple of 16 (rows start at unaligned bytes).  Widths >= 1024: the LDS-DMA ring kernel
+    (the right halo dword of a strip that ends within 3 bytes of the row end is fetched earlier and shifted: w % 1024 in 1..3);
+    GH_SOBEL_DMA_UNALIGNED=0 or narrower frames: the register-staged strip kernel on the first w & ~15 columns with unaligned
+    vector accesses + a per-pixel kernel for the rest (forced on for small frames here)."""
+    monkeypatch.setenv("GH_SOBEL_DMA_UNALIGNED", dma_unaligned)
     monkeypatch.setenv("GH_SOBEL_UNALIGNED_MIN_PX", "1")
     plane = oracle.frame_rand(w, h, 1, seed=w + h).reshape(h, w)
     want = oracle.sobel(plane)

@@ -1,45 +1,83 @@
 #!/usr/bin/env python3
-"""Randomised parity stress of the LDS-DMA kernels under memory-latency noise (developer tool, GPU box).
+"""Randomised parity stress of the LDS-DMA kernels under memory-latency noise (GPU box).
 
 The ring kernels do their own s_waitcnt vmcnt accounting; a wrong count would show up as rare, timing-dependent corrupt
-rows.  This loops for N seconds over random shapes / channel counts / modes / band heights / ring depths while a second
-stream hammers HBM with large copies, and compares every result with the oracle.   usage: stress_parity.py [seconds]"""
-import importlib, os, sys, time
+rows.  tests/test_isa_vmcnt.py checks the counts on the generated code; this is the dynamic counterpart: it loops for N
+seconds over random shapes (any width) / channel counts / modes / band heights / ring depths / dispatch orders while a second
+stream keeps 1 GiB of copy traffic in flight, and compares every result with the oracle.
+    usage: stress_parity.py [seconds] [seed]          (a bounded, seeded run is part of `pytest -m gpu`: tests/test_gpu_stress.py)"""
+import importlib
+import os
+import sys
+import time
+
 import numpy as np
-os.environ["GH_TUNE_DYNAMIC"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from oracle import pyoracle as O
-pkg = importlib.import_module("openmp-parallel-computing_amd"); api = pkg.hostapi; api.init(0)
-secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rnd = np.random.RandomState(int(time.time()) & 0xffff)
-noise_a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda"); noise_b = torch.empty_like(noise_a)
-side = torch.cuda.Stream()
-t_end, n, bad = time.time() + secs, 0, 0
-knob_sets = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": "4"}, {"GH_SOBEL_DMA": "2"}, {"GH_SOBEL_DMA": "4"}, {"GH_SOBEL_DMA": "8"},
-             {"GH_FUSED_DMA_R": "16", "GH_SOBEL_R": "16"}, {"GH_FUSED_DMA_R": "32", "GH_SOBEL_R": "32"}, {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"},
-             {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"}]
-allk = {k for d in knob_sets for k in d}
-while time.time() < t_end:
-    with torch.cuda.stream(side):                       # latency noise: 1 GiB of copy traffic in flight beside the kernels
-        for _ in range(4): noise_b.copy_(noise_a, non_blocking=True)
-    for k in allk: os.environ.pop(k, None)
-    os.environ.update(knob_sets[rnd.randint(len(knob_sets))])
-    w = 16 * int(rnd.randint(64, 520)); h = int(rnd.choice([1, 2, 3, 17, 63, 64, 65, 66, 127, 130, 257, 300])); ch = int(rnd.choice([3, 3, 4]))
-    if rnd.randint(4) == 0:                              # widths that are not multiples of 16: unaligned strips + column tail
-        w += int(rnd.randint(1, 16))
-        os.environ["GH_FUSED_UNALIGNED_MIN_PX"] = os.environ["GH_SOBEL_UNALIGNED_MIN_PX"] = "1"
-    mode = int(rnd.randint(2))
-    img = O.frame_rand(w, h, ch, seed=int(rnd.randint(1 << 30)))
-    d = torch.from_numpy(img).cuda()
-    luma = O.gray_to_plane(img, mode); want = O.sobel(luma)
-    outs = [api.gray_sobel_fused(d, mode) for _ in range(3)]
-    outs.append(api.sobel(torch.from_numpy(luma).cuda()))
-    torch.cuda.synchronize()
-    for o in outs:
-        n += 1
-        if not np.array_equal(o.cpu().numpy(), want):
-            bad += 1
-            print("MISMATCH", w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
-print(f"{n} results checked in {secs:.0f} s, {bad} mismatches")
-sys.exit(1 if bad else 0)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": "4"}, {"GH_SOBEL_DMA": "2"}, {"GH_SOBEL_DMA": "4"}, {"GH_SOBEL_DMA": "8"},
+             {"GH_FUSED_DMA_R": "16", "GH_SOBEL_R": "16"}, {"GH_FUSED_DMA_R": "32", "GH_SOBEL_R": "32"}, {"GH_FUSED_DMA_R": "7", "GH_SOBEL_R": "5"},
+             {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"}, {"GH_FUSED_DMA_ORDER": "4", "GH_SOBEL_ORDER": "4"},
+             {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"},
+             {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}]
+
+
+def run(secs: float, seed: int, verbose: bool = True):
+    """Returns (results checked, mismatches).  The library re-reads its knobs per launch only under GH_TUNE_DYNAMIC."""
+    os.environ["GH_TUNE_DYNAMIC"] = "1"
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    from oracle import pyoracle as O          # checker
+    pkg = importlib.import_module("openmp-parallel-computing_amd")
+    api = pkg.hostapi
+    api.init(0)
+    rnd = np.random.RandomState(seed)
+    noise_a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    noise_b = torch.empty_like(noise_a)
+    side = torch.cuda.Stream()
+    allk = {k for d in KNOB_SETS for k in d} | {"GH_FUSED_UNALIGNED_MIN_PX", "GH_SOBEL_UNALIGNED_MIN_PX"}
+    saved = {k: os.environ.get(k) for k in allk}
+    t_end, n, bad = time.time() + secs, 0, 0
+    try:
+        while time.time() < t_end:
+            with torch.cuda.stream(side):                       # latency noise: 1 GiB of copy traffic in flight beside the kernels
+                for _ in range(4):
+                    noise_b.copy_(noise_a, non_blocking=True)
+            for k in allk:
+                os.environ.pop(k, None)
+            os.environ.update(KNOB_SETS[rnd.randint(len(KNOB_SETS))])
+            w = 16 * int(rnd.randint(64, 520))
+            h = int(rnd.choice([1, 2, 3, 17, 63, 64, 65, 66, 127, 130, 257, 300]))
+            ch = int(rnd.choice([3, 3, 4]))
+            if rnd.randint(3) == 0:                              # widths that are not multiples of 16
+                w += int(rnd.randint(1, 16))
+                os.environ["GH_FUSED_UNALIGNED_MIN_PX"] = os.environ["GH_SOBEL_UNALIGNED_MIN_PX"] = "1"
+            mode = int(rnd.randint(2))
+            img = O.frame_rand(w, h, ch, seed=int(rnd.randint(1 << 30)))
+            d = torch.from_numpy(img).cuda()
+            luma = O.gray_to_plane(img, mode)
+            want = O.sobel(luma)
+            outs = [api.gray_sobel_fused(d, mode) for _ in range(3)]
+            outs.append(api.sobel(torch.from_numpy(luma).cuda()))
+            torch.cuda.synchronize()
+            for o in outs:
+                n += 1
+                if not np.array_equal(o.cpu().numpy(), want):
+                    bad += 1
+                    if verbose:
+                        print("MISMATCH", w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return n, bad
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else (int(time.time()) & 0xffff)
+    n, bad = run(secs, seed)
+    print(f"{n} results checked in {secs:.0f} s (seed {seed}), {bad} mismatches")
+    sys.exit(1 if bad else 0)
