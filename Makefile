@@ -18,7 +18,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: the IEEE luma model needs un-fused mul/add (FMA mode calls fmaf explicitly).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
-HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/streamed.hip $(CSRC)/comm.hip $(CSRC)/shim.hip
+HIP_SRCS := $(CSRC)/gray.hip $(CSRC)/sobel.hip $(CSRC)/fused.hip $(CSRC)/conv3x3.hip $(CSRC)/reduce.hip $(CSRC)/old_api.hip $(CSRC)/streamed.hip $(CSRC)/comm.hip $(CSRC)/shim.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := include/grayhip.h $(CSRC)/gh_common.h $(CSRC)/sobel_tile.h $(CSRC)/stream_core.h
 

@@ -14,6 +14,8 @@
  *   gh_conv3x3_rgb8_dev                   old/parallel_convolution.c:8-24   (u8 frames, zero border)
  *   gh_sum_rgb8_dev                       old/parallel_avg_pixel.c:5-42     (exact u64 channel sums)
  *   gh_mean_gray_minmax_dev               old/parallel_to_grayscale.c:7-38  (u8 frames)
+ *   gh_old_parallel_*                     old/parallel_convolution.c:8, old/parallel_avg_pixel.c:5,
+ *                                         old/parallel_to_grayscale.c:7     (historic signatures, long samples)
  *
  * Conventions
  *   - *_dev functions take DEVICE pointers, enqueue work on `stream` (a hipStream_t passed as
@@ -191,6 +193,22 @@ GH_API int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_
                                                int width, int rows, int channels, int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge,
                                                int width, int rows, gh_stream_t stream);
+
+/* ---- the reference's historic entry points over `long` samples (old/parallel_*.c) --------------------------
+ * Same argument meaning as the originals; the dimensions, compile-time macros of a utils.h that the reference does not
+ * contain, are run-time arguments (DIM_RGB = 3, DIM_KERNEL = 3, PAD = 2), and a status is returned.
+ *   img            row-major [rows][cols][3] longs (convolution: the PRE-PADDED [rows+2][cols+2][3] array; output (r, c)
+ *                  reads input rows r..r+2 and columns c..c+2)                         old/parallel_convolution.c:8,17
+ *   convolved_img  pointer tree [rows][cols] -> long[3]; the weighted sum is ADDED to what is there, then divided by
+ *                  gblur_norm with C integer division                                  old/parallel_convolution.c:17,21
+ *   avgs           long[3], accumulated into: avgs[c] = (avgs[c] + 3 * sum_c) / (rows * cols * 3)   old/parallel_avg_pixel.c:17-41
+ *   grayscale_img  pointer tree, R = G = B = (int)(r + g + b) / 3; min_max_gray = {min(256, ..), max(-1, ..)}
+ *                                                                                      old/parallel_to_grayscale.c:9-10,20-35
+ * Byte-valued frames run on the hot-path u8 kernels (narrowed on upload), anything else that fits 30 bits on plain 64-bit
+ * kernels; results equal the reference's arithmetic either way.  Parity status: unpinned (the old/ sources cannot be built here). */
+GH_API int gh_old_parallel_convolution(const long *img, const long kernel[9], long ***convolved_img, int rows, int cols, long gblur_norm);
+GH_API int gh_old_parallel_avg_pixel(const long *img, long *avgs, int rows, int cols);
+GH_API int gh_old_parallel_to_grayscale(const long *img, long ***grayscale_img, long *min_max_gray, int rows, int cols);
 
 /* The reference's own symbols (same prototypes as monolithic/include/ headers).  They return void in
  * the reference, so a failure is reported on stderr and the process is aborted -- never a

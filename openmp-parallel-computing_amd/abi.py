@@ -66,6 +66,9 @@ SIGNATURES = {
     "gh_sharded_sobel_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_gray_sobel_streamed_rows_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                    C.POINTER(C.c_double)]),
+    "gh_old_parallel_convolution": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int, C.c_int, C.c_long]),
+    "gh_old_parallel_avg_pixel": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_int]),
+    "gh_old_parallel_to_grayscale": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_int]),
     "convert_to_grayscale": (None, [_u8p, C.c_int, C.c_int, C.c_int]),
     "sobel_edge": (None, [_u8p, _u8p, C.c_int, C.c_int]),
     "gh_selftest_sobel_mag": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -321,6 +321,11 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     const int over = (xw + STRIP_PX < w) ? max(0, (xw + STRIP_PX) * CH + 4 - w * CH) : 0;   // wave-uniform: 0 or 1 (RGB8), 0 (RGBA8)
     if (lane != 0) hoff -= (uint32_t)over;
     const uint32_t rsh = 8u * (uint32_t)over;
+    // and on the left: a shifted last strip of an RGB8 frame may start at column 1 (w = 1025): "xw * 3 - 4" would be -1 (offsets
+    // are unsigned); the dword then starts at the row's first byte and is shifted up after the read
+    const int under = xw > 0 ? max(0, 4 - xw * CH) : 0;                                  // wave-uniform: 0 or 1
+    if (lane == 0) hoff += (uint32_t)under;
+    const uint32_t lsh = 8u * (uint32_t)under;
     const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
 
     StateF2 st;
@@ -359,7 +364,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
 #pragma unroll
         for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
         const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
-        const uint32_t hw = lane == 0 ? (CH == 3 ? (hh.x >> 8) : hh.x) : (hh.y >> rsh);
+        const uint32_t hw = lane == 0 ? (CH == 3 ? ((hh.x << lsh) >> 8) : hh.x) : (hh.y >> rsh);
         uint4 out;
         if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
         else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);

@@ -164,6 +164,11 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     const int over = xw + STRIP_PX < w ? max(0, xw + STRIP_PX + 4 - w) : 0;             // wave-uniform, 0 for aligned frames
     if (lane != 0) hoff -= (uint32_t)over;
     const uint32_t rsh = 8u * (uint32_t)over;
+    // likewise on the left: a shifted last strip may start at column 1..3 (w = 1025..1027); its left dword then starts at the
+    // row's first byte instead of before it (offsets are unsigned: "xw - 4" would be 4 GiB away) and is shifted up after the read
+    const int under = xw > 0 ? max(0, 4 - xw) : 0;                                      // wave-uniform, 0 for aligned frames
+    if (lane == 0) hoff += (uint32_t)under;
+    const uint32_t lsh = 8u * (uint32_t)under;
     const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
 
     StateF2 st;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
         uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
         uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
-        if (lane == 0) ql = hh.x;
+        if (lane == 0) ql = hh.x << lsh;
         if (lane == 63) qr = hh.y >> rsh;
         // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
         const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};

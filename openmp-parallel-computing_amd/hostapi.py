@@ -119,6 +119,62 @@ def avg_pixel(rgb: np.ndarray, avgs_in=(0, 0, 0)) -> list[int]:
     return out
 
 
+# ---- the reference's historic entry points over `long` samples (old/parallel_*.c) -----------------------------
+
+def _pointer_tree(data: np.ndarray):
+    """long*** view of a C-contiguous (rows, cols, 3) int64 array: rows -> cols -> long[3], as the historic callers built it.
+    Returns (address of the tree, keep-alive objects)."""
+    rows, cols = data.shape[:2]
+    base = data.ctypes.data
+    cells = (base + (np.arange(rows * cols, dtype=np.uint64) * 24)).astype(np.uint64).reshape(rows, cols)      # &data[r][c][0]
+    cells = np.ascontiguousarray(cells)
+    row_ptrs = np.ascontiguousarray(cells.ctypes.data + np.arange(rows, dtype=np.uint64) * (8 * cols))         # &cells[r][0]
+    return row_ptrs.ctypes.data, (cells, row_ptrs)
+
+
+def _long_array(a, shape) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    if a.shape != shape:
+        raise GrayHipError(f"expected an array of shape {shape}, got {a.shape}")
+    return a
+
+
+def old_parallel_convolution(img_padded, kernel, convolved_img: np.ndarray, gblur_norm: int) -> np.ndarray:
+    """old/parallel_convolution.c:8 -- img_padded (rows+2, cols+2, 3) longs, kernel 3x3 longs; the weighted sums are ADDED to
+    convolved_img (rows, cols, 3) int64 and divided by gblur_norm in place."""
+    if convolved_img.dtype != np.int64 or not convolved_img.flags["C_CONTIGUOUS"] or convolved_img.ndim != 3:
+        raise GrayHipError("convolved_img must be a C-contiguous (rows, cols, 3) int64 array")
+    rows, cols = convolved_img.shape[:2]
+    img = _long_array(img_padded, (rows + 2, cols + 2, 3))
+    k = _long_array(np.asarray(kernel).reshape(9), (9,))
+    tree, keep = _pointer_tree(convolved_img)
+    check(abi.load().gh_old_parallel_convolution(img.ctypes.data, k.ctypes.data_as(C.POINTER(C.c_long)), tree, rows, cols, int(gblur_norm)),
+          "parallel_convolution")
+    del keep
+    return convolved_img
+
+
+def old_parallel_avg_pixel(img, avgs_in=(0, 0, 0)) -> list:
+    """old/parallel_avg_pixel.c:5 -- avgs = (avgs_in + 3 * sum) / (rows * cols * 3)."""
+    img = np.ascontiguousarray(img, dtype=np.int64)
+    rows, cols = img.shape[:2]
+    avgs = np.asarray(avgs_in, dtype=np.int64).copy()
+    check(abi.load().gh_old_parallel_avg_pixel(img.ctypes.data, avgs.ctypes.data_as(C.POINTER(C.c_long)), rows, cols), "parallel_avg_pixel")
+    return [int(v) for v in avgs]
+
+
+def old_parallel_to_grayscale(img):
+    """old/parallel_to_grayscale.c:7 -- returns ((rows, cols, 3) int64 grey image, [min, max])."""
+    img = np.ascontiguousarray(img, dtype=np.int64)
+    rows, cols = img.shape[:2]
+    out = np.zeros((rows, cols, 3), dtype=np.int64)
+    mm = np.zeros(2, dtype=np.int64)
+    tree, keep = _pointer_tree(out)
+    check(abi.load().gh_old_parallel_to_grayscale(img.ctypes.data, tree, mm.ctypes.data_as(C.POINTER(C.c_long)), rows, cols), "parallel_to_grayscale")
+    del keep
+    return out, [int(mm[0]), int(mm[1])]
+
+
 # ---- device-resident operators (torch uint8 CUDA tensors) ------------------------------------
 
 def _dev_ptr(t) -> int:

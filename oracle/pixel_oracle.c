@@ -216,6 +216,50 @@ void orc_mean_gray_minmax(const uint8_t *rgb, uint8_t *out_rgb, size_t npix, int
     minmax[0] = lo; minmax[1] = hi;
 }
 
+/* ---- old/ historic functions on `long` samples (flat arrays instead of pointer trees; dimensions at run time) -------- */
+
+void orc_old_parallel_convolution(const long *img_padded, const long kernel[9], long *convolved_inout, int rows, int cols, long gblur_norm)
+{
+    /* old/parallel_convolution.c:12-23: convolved[r][c][p] += img[r+kr][c+kc][p] * kernel[kr][kc]; then /= GBLUR_NORM */
+    const size_t pitch = ((size_t)cols + 2) * 3;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            for (int p = 0; p < 3; ++p) {
+                long *o = &convolved_inout[((size_t)r * cols + c) * 3 + p];
+                for (int kr = 0; kr < 3; ++kr)
+                    for (int kc = 0; kc < 3; ++kc) *o += img_padded[(size_t)(r + kr) * pitch + (size_t)(c + kc) * 3 + p] * kernel[kr * 3 + kc];
+                *o /= gblur_norm;
+            }
+}
+
+void orc_old_parallel_avg_pixel(const long *img, long *avgs, int rows, int cols)
+{
+    /* old/parallel_avg_pixel.c:14-41: every channel is added once per iteration of the inner `pixel` loop (3x) */
+    long c1 = 0, c2 = 0, c3 = 0;
+    const long count = (long)rows * cols * 3;
+    for (long i = 0; i < (long)rows * cols; ++i)
+        for (int pixel = 0; pixel < 3; ++pixel) { c1 += img[3 * i]; c2 += img[3 * i + 1]; c3 += img[3 * i + 2]; }
+    avgs[0] += c1; avgs[1] += c2; avgs[2] += c3;
+    for (int p = 0; p < 3; ++p) avgs[p] /= count;
+}
+
+void orc_old_parallel_to_grayscale(const long *img, long *gray_rgb_out, long *min_max_gray, int rows, int cols)
+{
+    /* old/parallel_to_grayscale.c:9-37 */
+    int min_gray = 256, max_gray = -1;
+    for (long i = 0; i < (long)rows * cols; ++i) {
+        int sum = 0;
+        for (int pixel = 0; pixel < 3; ++pixel) sum += img[3 * i + pixel];
+        int g = sum / 3;
+        gray_rgb_out[3 * i] = gray_rgb_out[3 * i + 1] = gray_rgb_out[3 * i + 2] = g;
+        if (g < min_gray) min_gray = g;
+        if (g > max_gray) max_gray = g;
+    }
+    min_max_gray[0] = min_gray;
+    min_max_gray[1] = max_gray;
+}
+
 /* ---- synthetic frames ------------------------------------------------------------------ */
 
 static inline uint64_t splitmix_word(uint64_t seed, uint64_t j)

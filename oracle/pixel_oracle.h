@@ -73,6 +73,13 @@ void orc_avg_from_sums(const uint64_t sums[3], size_t npix, int64_t avgs_inout[3
  * (initial values 256 / -1 as in the reference, so an empty frame returns those) */
 void orc_mean_gray_minmax(const uint8_t *rgb, uint8_t *out_rgb, size_t npix, int32_t minmax[2]);
 
+/* the historic functions themselves on `long` samples, flat arrays, run-time dimensions:
+ * old/parallel_convolution.c:8-24 (pre-padded [rows+2][cols+2][3] input, += then /= norm),
+ * old/parallel_avg_pixel.c:5-42, old/parallel_to_grayscale.c:7-38 (gray_rgb_out = [rows][cols][3]) */
+void orc_old_parallel_convolution(const long *img_padded, const long kernel[9], long *convolved_inout, int rows, int cols, long gblur_norm);
+void orc_old_parallel_avg_pixel(const long *img, long *avgs, int rows, int cols);
+void orc_old_parallel_to_grayscale(const long *img, long *gray_rgb_out, long *min_max_gray, int rows, int cols);
+
 /* deterministic synthetic frames */
 void orc_fill_rand(uint8_t *buf, size_t nbytes, uint64_t seed);      /* SplitMix64 byte stream */
 void orc_fill_smooth(uint8_t *rgb, int width, int height);

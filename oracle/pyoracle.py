@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         L.orc_fill_rand.argtypes = [_u8p, C.c_size_t, C.c_uint64]
         L.orc_fill_smooth.argtypes = [_u8p, C.c_int, C.c_int]
         L.orc_fill_cube.argtypes = [_u8p]
+        _lp = C.POINTER(C.c_long)
+        L.orc_old_parallel_convolution.argtypes = [_lp, _lp, _lp, C.c_int, C.c_int, C.c_long]
+        L.orc_old_parallel_avg_pixel.argtypes = [_lp, _lp, C.c_int, C.c_int]
+        L.orc_old_parallel_to_grayscale.argtypes = [_lp, _lp, _lp, C.c_int, C.c_int]
         L.orc_isqrt.restype = C.c_uint32
         L.orc_isqrt.argtypes = [C.c_uint32]
         _lib = L
@@ -230,3 +234,34 @@ class RefLib:
 def have_ref(which: str = "ieee") -> bool:
     name = {"ieee": "libref_ieee.so", "fma": "libref_fma_native.so"}[which]
     return os.path.exists(os.path.join(REF_DIR, name))
+
+
+# ---- the historic functions on `long` arrays (old/parallel_*.c), restated with run-time dimensions ---------------------
+
+def _lp(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_long))
+
+
+def old_parallel_convolution(img_padded: np.ndarray, kernel, convolved_inout: np.ndarray, norm: int) -> np.ndarray:
+    """img_padded (rows+2, cols+2, 3) int64; convolved_inout (rows, cols, 3) int64, accumulated into and divided in place."""
+    rows, cols = convolved_inout.shape[:2]
+    assert img_padded.shape == (rows + 2, cols + 2, 3)
+    k = np.ascontiguousarray(np.asarray(kernel, dtype=np.int64).reshape(9))
+    lib().orc_old_parallel_convolution(_lp(img_padded), _lp(k), _lp(convolved_inout), rows, cols, int(norm))
+    return convolved_inout
+
+
+def old_parallel_avg_pixel(img: np.ndarray, avgs_in=(0, 0, 0)) -> list:
+    rows, cols = img.shape[:2]
+    avgs = np.asarray(avgs_in, dtype=np.int64).copy()
+    lib().orc_old_parallel_avg_pixel(_lp(img), _lp(avgs), rows, cols)
+    return [int(v) for v in avgs]
+
+
+def old_parallel_to_grayscale(img: np.ndarray):
+    rows, cols = img.shape[:2]
+    out = np.zeros((rows, cols, 3), dtype=np.int64)
+    mm = np.zeros(2, dtype=np.int64)
+    lib().orc_old_parallel_to_grayscale(_lp(img), _lp(out), _lp(mm), rows, cols)
+    return out, [int(mm[0]), int(mm[1])]
