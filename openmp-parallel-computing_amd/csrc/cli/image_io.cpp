@@ -335,6 +335,118 @@ void png_deflate_band(PngBand &b, const PngBand *prevband, bool last, int level)
     deflateEnd(&zs);
 }
 
+// ---- the reference's own zlib stream, byte for byte ------------------------------------------------------------------------
+// The reference writes its output with stb_image_write v1.16 (monolithic/src/main.c:41 -> stbi_write_png), whose built-in
+// compressor is a small deterministic LZ77 + fixed-Huffman coder.  A PNG FILE equal to the reference's (the
+// md5 of images/test_gray.png) needs the same parse of the filtered bytes, so this function restates that compressor's
+// decisions (monolithic/include/stb_image_write.h:866-1015, public domain / MIT, Sean Barrett): one final fixed-Huffman
+// block behind the header 78 5E; 3-byte hash (the shift/xor mix of :868-876) into 16384 buckets that keep the most recent
+// 8..16 positions (a bucket that holds 16 drops its oldest 8 before the next insert); among the candidates inside the 32 KiB
+// window the LAST one that is at least as long as the best so far wins (minimum 3, maximum 258); one-step lazy evaluation
+// (a strictly longer match at the next byte turns this byte into a literal); the last 3 bytes are literals; stored blocks of
+// <= 32767 bytes instead if that is smaller; Adler-32 trailer.  `quality` is stb's stbi_write_png_compression_level = 8.
+std::vector<uint8_t> zlib_like_the_reference(const uint8_t *data, size_t len)
+{
+    constexpr int kQuality = 8, kBuckets = 16384, kSlots = 2 * kQuality;
+    static const uint16_t len_base[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 259};
+    static const uint8_t len_extra[] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dist_base[] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193,
+                                         12289, 16385, 24577, 32768};
+    static const uint8_t dist_extra[] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    std::vector<uint8_t> out;
+    out.reserve(len / 2 + 64);
+    out.push_back(0x78);
+    out.push_back(0x5e);
+    uint32_t acc = 0;
+    int nacc = 0;
+    auto put = [&](uint32_t bits, int n) {               // deflate packs from the least significant bit
+        acc |= bits << nacc;
+        nacc += n;
+        while (nacc >= 8) { out.push_back((uint8_t)acc); acc >>= 8; nacc -= 8; }
+    };
+    auto put_code = [&](uint32_t code, int n) {          // Huffman codes go out most significant bit first
+        uint32_t r = 0;
+        for (int i = 0; i < n; ++i) { r = (r << 1) | (code & 1); code >>= 1; }
+        put(r, n);
+    };
+    auto put_symbol = [&](int sym) {                      // the fixed code of RFC 1951 3.2.6
+        if (sym <= 143) put_code(0x30 + sym, 8);
+        else if (sym <= 255) put_code(0x190 + sym - 144, 9);
+        else if (sym <= 279) put_code(sym - 256, 7);
+        else put_code(0xc0 + sym - 280, 8);
+    };
+    auto mix = [&](size_t at) {
+        uint32_t h = data[at] + ((uint32_t)data[at + 1] << 8) + ((uint32_t)data[at + 2] << 16);
+        h ^= h << 3; h += h >> 5; h ^= h << 4; h += h >> 17; h ^= h << 25; h += h >> 6;
+        return (int)(h & (kBuckets - 1));
+    };
+    auto run = [&](size_t a, size_t b, size_t limit) {   // common prefix of data[a..] and data[b..], at most 258 and `limit`
+        size_t n = 0;
+        const size_t cap = limit < 258 ? limit : 258;
+        while (n < cap && data[a + n] == data[b + n]) ++n;
+        return (int)n;
+    };
+    std::vector<int64_t> slot((size_t)kBuckets * kSlots);
+    std::vector<uint8_t> used(kBuckets, 0);
+    put(1, 1);                                            // BFINAL
+    put(1, 2);                                            // BTYPE = fixed Huffman
+    size_t i = 0;
+    while (i + 3 < len) {
+        const int b = mix(i);
+        int64_t *cand = &slot[(size_t)b * kSlots];
+        int best = 3;
+        int64_t where = -1;
+        for (int j = 0; j < used[b]; ++j)
+            if (cand[j] > (int64_t)i - 32768) {
+                const int d = run((size_t)cand[j], i, len - i);
+                if (d >= best) { best = d; where = cand[j]; }
+            }
+        if (used[b] == kSlots) {
+            memmove(cand, cand + kQuality, sizeof(int64_t) * kQuality);
+            used[b] = kQuality;
+        }
+        cand[used[b]++] = (int64_t)i;
+        if (where >= 0) {                                 // lazy evaluation
+            const int b2 = mix(i + 1);
+            const int64_t *c2 = &slot[(size_t)b2 * kSlots];
+            for (int j = 0; j < used[b2]; ++j)
+                if (c2[j] > (int64_t)i - 32767 && run((size_t)c2[j], i + 1, len - i - 1) > best) { where = -1; break; }
+        }
+        if (where >= 0) {
+            const int dist = (int)((int64_t)i - where);
+            int j = 0;
+            while (best > len_base[j + 1] - 1) ++j;
+            put_symbol(j + 257);
+            if (len_extra[j]) put((uint32_t)(best - len_base[j]), len_extra[j]);
+            j = 0;
+            while (dist > dist_base[j + 1] - 1) ++j;
+            put_code((uint32_t)j, 5);
+            if (dist_extra[j]) put((uint32_t)(dist - dist_base[j]), dist_extra[j]);
+            i += (size_t)best;
+        } else {
+            put_symbol(data[i]);
+            ++i;
+        }
+    }
+    for (; i < len; ++i) put_symbol(data[i]);
+    put_symbol(256);
+    while (nacc) put(0, 1);
+    if (out.size() > len + 2 + ((len + 32766) / 32767) * 5) {      // incompressible: stored blocks
+        out.resize(2);
+        for (size_t j = 0; j < len;) {
+            const size_t blk = len - j > 32767 ? 32767 : len - j;
+            out.push_back(len - j == blk ? 1 : 0);
+            out.push_back((uint8_t)blk); out.push_back((uint8_t)(blk >> 8));
+            out.push_back((uint8_t)~blk); out.push_back((uint8_t)(~blk >> 8));
+            out.insert(out.end(), data + j, data + j + blk);
+            j += blk;
+        }
+    }
+    const uLong ad = adler32(adler32(0L, Z_NULL, 0), data, (uInt)len);
+    for (int sh = 24; sh >= 0; sh -= 8) out.push_back((uint8_t)(ad >> sh));
+    return out;
+}
+
 }  // namespace
 
 bool gh_image_write_png(const std::string &path, int width, int height, int channels, const uint8_t *pixels, std::string &err)
@@ -344,6 +456,10 @@ bool gh_image_write_png(const std::string &path, int width, int height, int chan
     const size_t rb = (size_t)width * channels;
     const char *lv = getenv("GH_PNG_LEVEL");
     const int level = lv ? atoi(lv) : 3;       // gray / edge frames: level 3 output is as small as level 6, at half the time
+    // GRAYHIP_PNG=fast: band-parallel zlib deflate (any PNG reader decodes the same pixels, 3-10x faster to write);
+    // default: the reference's own byte stream (one IDAT, stb's compressor restated above) -- files compare equal with cmp
+    const char *pm = getenv("GRAYHIP_PNG");
+    const bool reference_bytes = !(pm && strcmp(pm, "fast") == 0) && (rb + 1) * (size_t)height < (1ull << 31);
 
     // bands: >= 256 KiB of rows each, at most 4 per hardware thread; GH_PNG_THREADS caps the worker count
     const size_t band_bytes = 256 * 1024;
@@ -369,20 +485,26 @@ bool gh_image_write_png(const std::string &path, int width, int height, int chan
         worker();
         for (auto &t : pool) t.join();
     };
-    parallel_for([&](int i) { png_filter_band(pixels, rb, channels, bands[i]); });
-    parallel_for([&](int i) { png_deflate_band(bands[i], i ? &bands[i - 1] : nullptr, i == nbands - 1, level); });
-
+    parallel_for([&](int i) { png_filter_band(pixels, rb, channels, bands[i]); });     // same filter choice as the reference either way
     std::vector<uint8_t> z;
-    z.push_back(0x78);
-    z.push_back(level >= 7 ? 0xDA : (level >= 6 ? 0x9C : (level >= 2 ? 0x5E : 0x01)));      // CMF/FLG: 32 KiB window, no dictionary
-    uLong adler = adler32(0L, Z_NULL, 0);
-    for (auto &b : bands) {
-        if (!b.ok) { err = "zlib deflate failed"; return false; }
-        z.insert(z.end(), b.z.begin(), b.z.end());
-        adler = adler32_combine(adler, b.adler, (z_off_t)b.filtered.size());
-        std::vector<uint8_t>().swap(b.z);
+    if (reference_bytes) {
+        std::vector<uint8_t> filtered;
+        filtered.reserve((rb + 1) * (size_t)height);
+        for (auto &b : bands) { filtered.insert(filtered.end(), b.filtered.begin(), b.filtered.end()); std::vector<uint8_t>().swap(b.filtered); }
+        z = zlib_like_the_reference(filtered.data(), filtered.size());
+    } else {
+        parallel_for([&](int i) { png_deflate_band(bands[i], i ? &bands[i - 1] : nullptr, i == nbands - 1, level); });
+        z.push_back(0x78);
+        z.push_back(level >= 7 ? 0xDA : (level >= 6 ? 0x9C : (level >= 2 ? 0x5E : 0x01)));      // CMF/FLG: 32 KiB window, no dictionary
+        uLong adler = adler32(0L, Z_NULL, 0);
+        for (auto &b : bands) {
+            if (!b.ok) { err = "zlib deflate failed"; return false; }
+            z.insert(z.end(), b.z.begin(), b.z.end());
+            adler = adler32_combine(adler, b.adler, (z_off_t)b.filtered.size());
+            std::vector<uint8_t>().swap(b.z);
+        }
+        for (int s = 24; s >= 0; s -= 8) z.push_back((uint8_t)(adler >> s));
     }
-    for (int s = 24; s >= 0; s -= 8) z.push_back((uint8_t)(adler >> s));
 
     std::vector<uint8_t> file;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};

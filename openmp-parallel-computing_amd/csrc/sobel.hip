@@ -246,6 +246,66 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
+#ifdef GH_ENABLE_PROBES
+// ---- access-pattern probe: "band march" -- a wave owns RW rows and marches ALONG them, 1 KiB per step -------------------------
+// The strip kernels above walk DOWN a 1 KiB-wide strip; their no-arithmetic skeleton runs as fast as the real kernel, i.e. the
+// traversal, not the arithmetic, is the limit.  This probe moves the same bytes (RW + 2 input rows in, RW rows out per wave and
+// step, LDS-DMA ring of two steps) with the other traversal.  Output = a copy of the middle rows (not a Sobel result).
+template <int RW>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_march_probe(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int skew)
+{
+    using namespace stream_core;
+    constexpr int NR = RW + 2;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][2][NR][STRIP_PX];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y0 = ((int)blockIdx.x * WAVES_PER_BLOCK + wave) * RW;
+    if (y0 >= rows) return;
+    const int nsteps = w / STRIP_PX;
+    const int start = (int)(((unsigned)blockIdx.x * (unsigned)skew) % (unsigned)nsteps);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0][0];
+    auto issue = [&](int step, int slot) {
+        int sx = start + step; if (sx >= nsteps) sx -= nsteps;
+        const uint32_t voff = (uint32_t)sx * STRIP_PX + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int yy = y0 - 1 + r; yy = yy < 0 ? 0 : (yy >= rows ? rows - 1 : yy);
+            const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+            const uint32_t d = uniform_u32(lds0 + (uint32_t)(slot * NR + r) * STRIP_PX);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rowb), "s"(d) : "memory");
+        }
+    };
+    issue(0, 0);
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        const int slot = step & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (step + 1 < nsteps) {
+            if (slot == 0) issue(step + 1, 1); else issue(step + 1, 0);
+            // younger than this step's DMA: the next step's NR pieces + (from the second step on) the RW stores of the previous step
+            if (step >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR + RW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        int sx = start + step; if (sx >= nsteps) sx -= nsteps;
+        uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&ring[wave][slot][r][16 * lane]);
+            if (r == 0 || r == NR - 1) { acc.x ^= q.x & 1u; continue; }       // halo rows: read, keep alive, not stored
+            uint4 o = q;
+            o.x ^= acc.x & 0u;
+            const int y = y0 + r - 1;
+            if (y < rows) store_strip(dst + (size_t)y * w + (size_t)sx * STRIP_PX, lane, o);
+            else asm volatile("s_nop 0" ::: "memory");
+        }
+    }
+}
+#endif
+
 using stream_core::row_readable;
 
 __global__ __launch_bounds__(BLOCK) void k_sobel_tiled(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
@@ -415,6 +475,15 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES
+            else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW
+                const int rw = dma - 100, skew = GH_TUNE_INT("GH_SOBEL_SKEW", 3);
+                const unsigned gm = (unsigned)((rows + 4 * rw - 1) / (4 * rw));
+                if (rw == 4) k_march_probe<4><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+                else if (rw == 6) k_march_probe<6><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+                else if (rw == 8) k_march_probe<8><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+                else if (rw == 14) k_march_probe<14><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+                else k_march_probe<2><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+            }
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
             else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
             else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);  // probe: default-policy DMA loads

@@ -63,11 +63,20 @@ def test_gray_cli_reproduces_the_reference_golden_file(tmp_path):
     img = np.asarray(Image.open(out))
     assert img.shape == (1080, 1920, 3)
     assert hashlib.sha256(np.ascontiguousarray(img).data).hexdigest() == full["gray_ieee_rgb_sha256"]
+    # ... and the FILE is the reference's committed images/test_gray.png, byte for byte
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["test_jpg"]
+    assert hashlib.md5(out.read_bytes()).hexdigest() == ka["golden_png_md5"]
     p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out, 2)
     assert p.returncode == 0 and p.stdout.startswith("Compute kernel ×2: ")
     assert hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest() == full["cli_gray_p2_rgb_sha256"]
+    assert hashlib.md5(out.read_bytes()).hexdigest() == ka["cli_gray_ieee_p2_png_md5"]
     p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out, env={"GRAYHIP_MODE": "fma"})
     assert hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest() == full["gray_fma_rgb_sha256"]
+    assert hashlib.md5(out.read_bytes()).hexdigest() == ka["cli_gray_fma_p1_png_md5"]
+    # GRAYHIP_PNG=fast: the band-parallel encoder -- another byte stream, the same pixels
+    p = run(GRAY, os.path.join(GOLDEN, "test.jpg"), out, env={"GRAYHIP_PNG": "fast"})
+    assert p.returncode == 0 and hashlib.md5(out.read_bytes()).hexdigest() != ka["golden_png_md5"]
+    assert hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest() == full["gray_ieee_rgb_sha256"]
 
 
 @pytest.mark.gpu
@@ -80,6 +89,8 @@ def test_sobel_cli_matches_reference_cli(tmp_path):
         assert re.fullmatch(rf"Compute kernel \(grayscale \+ sobel\) ×{passes}: \d+\.\d{{4}} s\n", p.stdout)
         got = hashlib.sha256(np.ascontiguousarray(np.asarray(Image.open(out))).data).hexdigest()
         assert got == full[f"cli_sobel_p{passes}_rgb_sha256"], passes
+        ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["test_jpg"]
+        assert hashlib.md5(out.read_bytes()).hexdigest() == ka[f"cli_sobel_ieee_p{passes}_png_md5"], passes     # file-level parity
 
 
 @pytest.mark.gpu

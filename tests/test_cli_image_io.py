@@ -125,6 +125,60 @@ def test_generated_jpegs_decode_like_the_reference(tmp_path, name, size, mode, o
     assert np.array_equal(mine, theirs), f"{name}: {np.count_nonzero(mine != theirs)} bytes differ"
 
 
+STB_ENC = os.path.join(ROOT, "oracle", "_ref", "stb_encode")
+
+
+def test_png_file_equals_the_reference_golden_file(tmp_path, oracle):
+    """File-level parity: the reference's committed images/test_gray.png is the IEEE grey of images/test.jpg
+    written by stb_image_write; this repo's decoder + the (oracle's) grey + this repo's PNG writer give the same FILE -- the
+    md5 the survey recorded.  No GPU involved: the GPU form of this check is tests/test_cli_contract.py."""
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["test_jpg"]
+    rgb = decode(os.path.join(GOLDEN, "test.jpg"), tmp_path)
+    grey = oracle.gray_inplace(rgb, oracle.MODE_IEEE)
+    path = tmp_path / "g.png"
+    encode(grey, path, tmp_path)
+    assert hashlib.md5(path.read_bytes()).hexdigest() == ka["golden_png_md5"]
+
+
+@pytest.mark.skipif(not os.access(STB_ENC, os.X_OK), reason="the reference's PNG writer is compiled only where /root/reference exists")
+@pytest.mark.parametrize("w,h,c,kind", [(1, 1, 1, "noise"), (2, 3, 3, "noise"), (7, 5, 2, "smooth"), (53, 37, 3, "smooth"), (64, 64, 4, "noise"),
+                                        (300, 2, 3, "flat"), (2, 300, 1, "smooth"), (640, 480, 3, "photo"), (1000, 3, 4, "photo"),
+                                        (257, 129, 1, "noise"), (33000, 1, 1, "flat"), (40, 900, 3, "flat")])
+def test_png_files_equal_the_reference_writer(tmp_path, w, h, c, kind):
+    """Byte-identical PNG files with the reference's writer (stb_image_write v1.16 compiled in place) on frames that exercise
+    every branch of its compressor: long runs (length 258, distances up to the window), incompressible noise (stored-block
+    fallback), every filter type, 1..4 channels, the 3-byte tail."""
+    rng = np.random.RandomState(w * 7 + h * 3 + c)
+    shape = (h, w, c) if c > 1 else (h, w)
+    if kind == "noise":
+        arr = rng.randint(0, 256, size=shape, dtype=np.uint8)
+    elif kind == "flat":
+        arr = np.full(shape, 200, dtype=np.uint8)
+        arr.reshape(-1)[:: max(1, arr.size // 11)] = 3
+    elif kind == "smooth":
+        arr = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] % 256).astype(np.uint8)
+        arr = np.repeat(arr, c, axis=2) if c > 1 else arr[..., 0]
+    else:
+        arr = _photo_like(w, h, seed=w + h)[..., :c] if c <= 3 else np.concatenate([_photo_like(w, h, seed=w + h), np.full((h, w, 1), 255, np.uint8)], axis=2)
+    arr = np.ascontiguousarray(arr)
+    mine, theirs = tmp_path / "mine.png", tmp_path / "theirs.png"
+    encode(arr, mine, tmp_path)
+    raw = tmp_path / "r.raw"
+    arr.tofile(raw)
+    subprocess.run([STB_ENC, str(w), str(h), str(c), str(raw), str(theirs)], check=True, capture_output=True)
+    assert mine.read_bytes() == theirs.read_bytes()
+
+
+def test_fast_png_mode_writes_the_same_pixels(tmp_path, monkeypatch):
+    arr = _photo_like(333, 211, seed=5)
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    encode(arr, a, tmp_path)
+    monkeypatch.setenv("GRAYHIP_PNG", "fast")
+    encode(arr, b, tmp_path)
+    assert a.read_bytes() != b.read_bytes()
+    assert np.array_equal(np.asarray(Image.open(a)), arr) and np.array_equal(np.asarray(Image.open(b)), arr)
+
+
 @pytest.mark.parametrize("w,h,c", [(1, 1, 1), (7, 3, 2), (53, 37, 3), (64, 64, 4), (300, 2, 3), (2, 300, 1)])
 def test_png_encode_roundtrip(tmp_path, w, h, c):
     rng = np.random.RandomState(w * 100 + h + c)
