@@ -215,22 +215,28 @@ private:
 // ---- inverse DCT: stb_image.h:2425-2520 (STBI__IDCT_1D / stbi__idct_block), restated ------------------------------------
 inline int fx(double v) { return (int)(v * 4096 + 0.5); }       // stbi__f2f: 12-bit fixed point constants
 
-struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
+// All sums and products wrap modulo 2^32 (unsigned arithmetic, reinterpreted as signed for the shifts): valid streams stay
+// far inside 32 bits, and for hostile ones (16-bit quantisers times large coefficients) this is what the reference's plain
+// `int` code does on a two's-complement machine, without the undefined behaviour.
+struct Idct1D { uint32_t x0, x1, x2, x3, t0, t1, t2, t3; };
 
 // one 8-point pass: even part into x0..x3, odd part into t0..t3 (results are x_k +- t_{3-k})
-inline Idct1D idct_pass(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+inline Idct1D idct_pass(int i0, int i1, int i2, int i3, int i4, int i5, int i6, int i7)
 {
-    static const int c0541 = fx(0.5411961f), c1847 = fx(-1.847759065f), c0765 = fx(0.765366865f), c1175 = fx(1.175875602f),
-                     c0298 = fx(0.298631336f), c2053 = fx(2.053119869f), c3072 = fx(3.072711026f), c1501 = fx(1.501321110f),
-                     c0899 = fx(-0.899976223f), c2562 = fx(-2.562915447f), c1961 = fx(-1.961570560f), c0390 = fx(-0.390180644f);
+    static const uint32_t c0541 = (uint32_t)fx(0.5411961f), c1847 = (uint32_t)fx(-1.847759065f), c0765 = (uint32_t)fx(0.765366865f),
+                          c1175 = (uint32_t)fx(1.175875602f), c0298 = (uint32_t)fx(0.298631336f), c2053 = (uint32_t)fx(2.053119869f),
+                          c3072 = (uint32_t)fx(3.072711026f), c1501 = (uint32_t)fx(1.501321110f), c0899 = (uint32_t)fx(-0.899976223f),
+                          c2562 = (uint32_t)fx(-2.562915447f), c1961 = (uint32_t)fx(-1.961570560f), c0390 = (uint32_t)fx(-0.390180644f);
+    const uint32_t s0 = (uint32_t)i0, s1 = (uint32_t)i1, s2 = (uint32_t)i2, s3 = (uint32_t)i3, s4 = (uint32_t)i4, s5 = (uint32_t)i5,
+                   s6 = (uint32_t)i6, s7 = (uint32_t)i7;
     Idct1D r;
-    const int e = (s2 + s6) * c0541;
-    const int even_lo = e + s6 * c1847, even_hi = e + s2 * c0765;
-    const int sum = (s0 + s4) * 4096, dif = (s0 - s4) * 4096;
+    const uint32_t e = (s2 + s6) * c0541;
+    const uint32_t even_lo = e + s6 * c1847, even_hi = e + s2 * c0765;
+    const uint32_t sum = (s0 + s4) * 4096u, dif = (s0 - s4) * 4096u;
     r.x0 = sum + even_hi; r.x3 = sum - even_hi; r.x1 = dif + even_lo; r.x2 = dif - even_lo;
-    const int a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
-    const int z = (a + b) * c1175;
-    const int pc = z + c * c0899, pd = z + d * c2562, pa = a * c1961, pb = b * c0390;
+    const uint32_t a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
+    const uint32_t z = (a + b) * c1175;
+    const uint32_t pc = z + c * c0899, pd = z + d * c2562, pa = a * c1961, pb = b * c0390;
     r.t0 = s7 * c0298 + pc + pa;
     r.t1 = s5 * c2053 + pd + pb;
     r.t2 = s3 * c3072 + pd + pa;
@@ -239,6 +245,7 @@ inline Idct1D idct_pass(int s0, int s1, int s2, int s3, int s4, int s5, int s6, 
 }
 
 inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+inline int sar(uint32_t v, int n) { return (int)(int32_t)v >> n; }        // arithmetic shift of the wrapped value
 
 void idct8x8(uint8_t *out, int stride, const int16_t in[64])
 {
@@ -248,21 +255,21 @@ void idct8x8(uint8_t *out, int stride, const int16_t in[64])
         Idct1D r = idct_pass(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56]);
         r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
         int *m = mid + col;
-        m[0] = (r.x0 + r.t3) >> 10;  m[56] = (r.x0 - r.t3) >> 10;
-        m[8] = (r.x1 + r.t2) >> 10;  m[48] = (r.x1 - r.t2) >> 10;
-        m[16] = (r.x2 + r.t1) >> 10; m[40] = (r.x2 - r.t1) >> 10;
-        m[24] = (r.x3 + r.t0) >> 10; m[32] = (r.x3 - r.t0) >> 10;
+        m[0] = sar(r.x0 + r.t3, 10);  m[56] = sar(r.x0 - r.t3, 10);
+        m[8] = sar(r.x1 + r.t2, 10);  m[48] = sar(r.x1 - r.t2, 10);
+        m[16] = sar(r.x2 + r.t1, 10); m[40] = sar(r.x2 - r.t1, 10);
+        m[24] = sar(r.x3 + r.t0, 10); m[32] = sar(r.x3 - r.t0, 10);
     }
     for (int row = 0; row < 8; ++row) {                  // rows: 12 + 2 + 3 bits to remove, rounding and the +128 level shift folded in
         const int *m = mid + 8 * row;
         Idct1D r = idct_pass(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-        const int bias = 65536 + (128 << 17);
+        const uint32_t bias = 65536u + (128u << 17);
         r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
         uint8_t *o = out + (size_t)row * stride;
-        o[0] = clamp8((r.x0 + r.t3) >> 17); o[7] = clamp8((r.x0 - r.t3) >> 17);
-        o[1] = clamp8((r.x1 + r.t2) >> 17); o[6] = clamp8((r.x1 - r.t2) >> 17);
-        o[2] = clamp8((r.x2 + r.t1) >> 17); o[5] = clamp8((r.x2 - r.t1) >> 17);
-        o[3] = clamp8((r.x3 + r.t0) >> 17); o[4] = clamp8((r.x3 - r.t0) >> 17);
+        o[0] = clamp8(sar(r.x0 + r.t3, 17)); o[7] = clamp8(sar(r.x0 - r.t3, 17));
+        o[1] = clamp8(sar(r.x1 + r.t2, 17)); o[6] = clamp8(sar(r.x1 - r.t2, 17));
+        o[2] = clamp8(sar(r.x2 + r.t1, 17)); o[5] = clamp8(sar(r.x2 - r.t1, 17));
+        o[3] = clamp8(sar(r.x3 + r.t0, 17)); o[4] = clamp8(sar(r.x3 - r.t0, 17));
     }
 }
 
@@ -491,8 +498,8 @@ bool JpegDecoder::block_sequential(Component &c, int16_t *blk)          // T.81 
     memset(blk, 0, 64 * sizeof(int16_t));
     const int t = dct.decode(bits_);
     if (t < 0 || t > 15) return fail("invalid DC difference category");
-    c.dc_pred += bits_.take_signed(t);
-    blk[0] = (int16_t)(c.dc_pred * q[0]);
+    c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)bits_.take_signed(t));
+    blk[0] = (int16_t)((uint32_t)c.dc_pred * q[0]);
     for (int k = 1; k < 64;) {
         const int rs = act.decode(bits_);
         if (rs < 0) return fail("invalid AC code");
@@ -504,7 +511,7 @@ bool JpegDecoder::block_sequential(Component &c, int16_t *blk)          // T.81 
         }
         k += run;
         if (k > 63) return fail("AC run passes the end of the block");
-        blk[kNatural[k]] = (int16_t)(bits_.take_signed(size) * q[k]);
+        blk[kNatural[k]] = (int16_t)((uint32_t)bits_.take_signed(size) * q[k]);
         ++k;
     }
     return true;
@@ -517,8 +524,8 @@ bool JpegDecoder::block_dc_progressive(Component &c, int16_t *blk)      // T.81 
         if (!dct.defined) return fail("scan uses a Huffman table that was never defined");
         const int t = dct.decode(bits_);
         if (t < 0 || t > 15) return fail("invalid DC difference category");
-        c.dc_pred += bits_.take_signed(t);
-        blk[0] = (int16_t)(c.dc_pred * (1 << al_));
+        c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)bits_.take_signed(t));
+        blk[0] = (int16_t)((uint32_t)c.dc_pred << al_);
     } else if (bits_.bit()) {
         blk[0] = (int16_t)(blk[0] + (1 << al_));
     }
@@ -545,7 +552,7 @@ bool JpegDecoder::block_ac_first(Component &c, int16_t *blk)            // T.81 
         }
         k += run;
         if (k > 63) return fail("AC run passes the end of the block");
-        blk[kNatural[k]] = (int16_t)(bits_.take_signed(size) * (1 << al_));
+        blk[kNatural[k]] = (int16_t)((uint32_t)bits_.take_signed(size) << al_);
         ++k;
     }
     return true;
@@ -684,7 +691,7 @@ void JpegDecoder::reconstruct_progressive()
         for (int by = 0; by < bh; ++by)
             for (int bx = 0; bx < bw; ++bx) {
                 int16_t *blk = c.coef.data() + ((size_t)by * c.blocks_w + bx) * 64;
-                for (int k = 0; k < 64; ++k) blk[kNatural[k]] = (int16_t)(blk[kNatural[k]] * q[k]);
+                for (int k = 0; k < 64; ++k) blk[kNatural[k]] = (int16_t)((uint32_t)(int)blk[kNatural[k]] * q[k]);
                 idct8x8(c.plane.data() + (size_t)by * 8 * c.stride + (size_t)bx * 8, c.stride, blk);
             }
     }

@@ -26,7 +26,7 @@ io, oo = a.in_offset_rows, a.out_offset_rows
 rgb = torch.randint(0, 256, (H + io, W, 3), dtype=torch.uint8, device="cuda")[io:]
 plane = torch.randint(0, 256, (H + io, W), dtype=torch.uint8, device="cuda")[io:]
 out = torch.empty((H + oo, W), dtype=torch.uint8, device="cuda")[oo:]
-rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda") if a.op == "fused4" else None
+rgba = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda") if a.op in ("fused4", "gray4", "inplace4") else None
 out3 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda") if a.op in ("conv", "minmax") else None
 scr = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda") if a.op in ("inplace", "replicate") else None
 mm = torch.tensor([256, -1], dtype=torch.int32, device="cuda")
@@ -38,6 +38,8 @@ ops = {"fused": (lambda: api.gray_sobel_fused(rgb, 0, out=out), 4), "sobel": (la
        "replicate": (lambda: api.replicate_plane(plane, scr), 4),
        "grayplane": (lambda: api.gray_of_plane(plane, 0, out=out), 2),
        "fused4": (lambda: api.gray_sobel_fused(rgba, 0, out=out), 5),
+       "gray4": (lambda: api.gray_to_plane(rgba, 0, out=out), 5),
+       "inplace4": (lambda: api.gray_inplace(rgba, 0), 8),
        "conv": (lambda: api.conv3x3(rgb, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16, out=out3), 6),
        "minmax": (lambda: pkg.abi.check(pkg.abi.load().gh_mean_gray_minmax_dev(rgb.data_ptr(), out3.data_ptr(), W * H, mm.data_ptr(), torch.cuda.current_stream().cuda_stream)), 6),
        "sum": (lambda: pkg.abi.check(pkg.abi.load().gh_sum_rgb8_dev(rgb.data_ptr(), W * H, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)), 3)}

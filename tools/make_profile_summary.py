@@ -85,7 +85,7 @@ for k, c in acc.items():
         continue
     f, w = whole_frame(c["FETCH_SIZE"]), whole_frame(c["WRITE_SIZE"])
     rd, wr = f["median"] * 1024 * 2, w["median"] * 1024
-    algo = ALGO[k] * NPIX
+    algo = ALGO[k] * NPIX if k != "k_copy_stream" else 2 * 3 * NPIX          # the copy probe moves the 805 MB RGB frame: 1 R + 1 W of it
     traffic["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches_averaged": [f["launches"] - f["outliers_beyond_2pct"],
                                                                                            w["launches"] - w["outliers_beyond_2pct"]],
                              "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_total_bytes": rd + wr, "algorithmic_bytes": algo,
