@@ -383,6 +383,13 @@ std::vector<uint8_t> zlib_like_the_reference(const uint8_t *data, size_t len)
     auto run = [&](size_t a, size_t b, size_t limit) {   // common prefix of data[a..] and data[b..], at most 258 and `limit`
         size_t n = 0;
         const size_t cap = limit < 258 ? limit : 258;
+        while (n + 8 <= cap) {                            // eight bytes at a time (b + cap <= len: both reads stay inside the data)
+            uint64_t x, y;
+            memcpy(&x, data + a + n, 8);
+            memcpy(&y, data + b + n, 8);
+            if (x != y) return (int)(n + (size_t)(__builtin_ctzll(x ^ y) >> 3));
+            n += 8;
+        }
         while (n < cap && data[a + n] == data[b + n]) ++n;
         return (int)n;
     };
@@ -398,6 +405,8 @@ std::vector<uint8_t> zlib_like_the_reference(const uint8_t *data, size_t len)
         int64_t where = -1;
         for (int j = 0; j < used[b]; ++j)
             if (cand[j] > (int64_t)i - 32768) {
+                // (a candidate that differs at byte best-1 is shorter than the best so far: it cannot win -- skipped without counting)
+                if (data[(size_t)cand[j] + best - 1] != data[i + best - 1]) continue;
                 const int d = run((size_t)cand[j], i, len - i);
                 if (d >= best) { best = d; where = cand[j]; }
             }
@@ -409,8 +418,10 @@ std::vector<uint8_t> zlib_like_the_reference(const uint8_t *data, size_t len)
         if (where >= 0) {                                 // lazy evaluation
             const int b2 = mix(i + 1);
             const int64_t *c2 = &slot[(size_t)b2 * kSlots];
-            for (int j = 0; j < used[b2]; ++j)
-                if (c2[j] > (int64_t)i - 32767 && run((size_t)c2[j], i + 1, len - i - 1) > best) { where = -1; break; }
+            if (i + 1 + (size_t)best < len)               // a longer match at i+1 needs best+1 bytes to exist at all
+                for (int j = 0; j < used[b2]; ++j)
+                    if (c2[j] > (int64_t)i - 32767 && data[(size_t)c2[j] + best] == data[i + 1 + best] &&
+                        run((size_t)c2[j], i + 1, len - i - 1) > best) { where = -1; break; }
         }
         if (where >= 0) {
             const int dist = (int)((int64_t)i - where);

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 img = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "test.jpg")
 tmp = tempfile.mkdtemp()
 sock = os.path.join(tmp, "gh.sock")
+# the server's own environment decides its PNG writer (GRAYHIP_PNG=fast: band-parallel; default: the reference's byte stream)
 srv = subprocess.Popen([os.path.join(ROOT, "bin", "grayhipd"), sock], stdout=subprocess.PIPE, text=True)
 srv.stdout.readline()
 exe = os.path.join(ROOT, "bin", "grayscale")
