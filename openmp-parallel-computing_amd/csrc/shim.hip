@@ -12,7 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
+#include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -243,6 +247,62 @@ int gh_gray_passes_host(unsigned char *data, int width, int height, int channels
     if (int rc = gh_ensure_init()) return rc;
     std::lock_guard<std::mutex> lk(g_host_mu);
     if (int rc = g_img.reserve(nbytes)) return rc;
+    // Large frames: the pixels are independent, so the frame goes through in chunks -- an uploader thread copies chunk k+1
+    // host -> device while this thread runs the kernel on chunk k and copies it back: PCIe is full duplex, the two directions
+    // overlap (16384^2 RGB8: 29 ms -> see DESIGN.md section 5).  Small frames: one upload, one launch, one download.
+    const size_t chunk_px = (size_t)GH_TUNE_INT("GH_HOST_CHUNK_MPX", 16) << 20;          // multiple of 1024 px: whole wavefront groups
+    if (nbytes >= ((size_t)GH_TUNE_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && chunk_px > 0 && npix > 2 * chunk_px) {
+        const int nchunk = (int)((npix + chunk_px - 1) / chunk_px);
+        static hipStream_t s_up = nullptr, s_dn = nullptr;
+        if (!s_up) { GH_HIP_TRY(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)); GH_HIP_TRY(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking)); }
+        std::vector<hipEvent_t> up(nchunk, nullptr), k0(nchunk, nullptr), k1(nchunk, nullptr);
+        auto cleanup = [&] { for (auto *v : {&up, &k0, &k1}) for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e); };
+        for (int k = 0; k < nchunk; ++k)
+            if (hipEventCreateWithFlags(&up[k], hipEventDisableTiming) != hipSuccess || hipEventCreate(&k0[k]) != hipSuccess || hipEventCreate(&k1[k]) != hipSuccess) {
+                cleanup();
+                return gh_set_error(GH_ERR_HIP, "hipEventCreate failed");
+            }
+        uint8_t *dev = (uint8_t *)g_img.p;
+        std::atomic<int> recorded{0};                 // chunks whose upload event has been RECORDED (a wait on an unrecorded event is a no-op)
+        std::atomic<int> up_failed{0};
+        hipError_t up_err = hipSuccess;
+        std::thread uploader([&] {
+            hipError_t ue = hipSetDevice(g_device);
+            for (int k = 0; k < nchunk && ue == hipSuccess; ++k) {
+                const size_t p0 = (size_t)k * chunk_px, n = std::min(chunk_px, npix - p0);
+                ue = hipMemcpyAsync(dev + p0 * channels, data + p0 * channels, n * channels, hipMemcpyHostToDevice, s_up);
+                if (ue == hipSuccess) ue = hipEventRecord(up[k], s_up);
+                if (ue == hipSuccess) recorded.store(k + 1, std::memory_order_release);
+            }
+            if (ue != hipSuccess) { up_err = ue; up_failed.store(1, std::memory_order_release); }
+        });
+        int rc = GH_OK;
+        hipError_t e = hipSuccess;
+        int issued = 0;
+        for (int k = 0; k < nchunk && rc == GH_OK && e == hipSuccess; ++k) {
+            const size_t p0 = (size_t)k * chunk_px, n = std::min(chunk_px, npix - p0);
+            while (recorded.load(std::memory_order_acquire) <= k && !up_failed.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (up_failed.load(std::memory_order_acquire)) break;
+            e = hipStreamWaitEvent(s_dn, up[k], 0);
+            if (e != hipSuccess) break;
+            e = hipEventRecord(k0[k], s_dn);
+            rc = gh_gray_inplace_passes_dev(dev + p0 * channels, n, channels, mode, passes, s_dn);
+            if (rc == GH_OK) e = hipEventRecord(k1[k], s_dn);
+            if (rc == GH_OK && e == hipSuccess) e = hipMemcpyAsync(data + p0 * channels, dev + p0 * channels, n * channels, hipMemcpyDeviceToHost, s_dn);
+            issued = k + 1;
+        }
+        uploader.join();
+        if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
+        (void)hipStreamSynchronize(s_up);
+        double secs = 0.0;
+        for (int k = 0; k < issued && e == hipSuccess; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, k0[k], k1[k]) == hipSuccess) secs += ms * 1e-3; }
+        if (kernel_seconds) *kernel_seconds = secs;
+        cleanup();
+        if (rc != GH_OK) return rc;
+        if (up_failed.load()) return gh_set_error(GH_ERR_HIP, "chunked upload failed: %s", hipGetErrorString(up_err));
+        if (e != hipSuccess) return gh_set_error(GH_ERR_HIP, "chunked gray pipeline failed: %s", hipGetErrorString(e));
+        return GH_OK;
+    }
     GH_HIP_TRY(hipMemcpy(g_img.p, data, nbytes, hipMemcpyHostToDevice));
     EventTimer t;
     if (int rc = t.start(nullptr)) return rc;

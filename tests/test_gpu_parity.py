@@ -309,6 +309,23 @@ def test_host_pointer_shims(pkg, oracle, jpg_crop, cli_crop):
     assert np.array_equal(rgba[..., 0], cli_crop["gray_rgba_p1_c0"]) and np.array_equal(rgba[..., 3], cli_crop["rgba_alpha"])
 
 
+@pytest.mark.parametrize("w,h,c,passes", [(2048, 1100, 3, 1), (2000, 1237, 4, 3), (4096, 1025, 3, 2)])
+def test_host_shim_chunked_pipeline(pkg, oracle, w, h, c, passes, monkeypatch):
+    """Large frames go through convert_to_grayscale's host entry point in chunks (an uploader thread copies chunk k+1 up while chunk
+    k is converted and copied back); forced here on small frames: 1 Mpixel chunks, no size threshold."""
+    monkeypatch.setenv("GH_HOST_CHUNK_MPX", "1")
+    monkeypatch.setenv("GH_HOST_PIPELINE_MIN_MB", "0")
+    img = oracle.frame_rand(w, h, c, seed=w + h + c)
+    for mode in (0, 1):
+        buf = img.copy()
+        secs = pkg.hostapi.gray_passes(buf, w, h, c, passes, mode)
+        assert secs > 0
+        assert np.array_equal(buf, oracle.gray_passes(img, passes, mode)), (mode,)
+    buf = img.copy()
+    pkg.convert_to_grayscale(buf, w, h, c)                       # the reference-named symbol, default mode
+    assert np.array_equal(buf, oracle.gray_inplace(img, 0))
+
+
 @pytest.mark.parametrize("name", ["rand1_1024x1024", "rand1_1021x517"])
 def test_old_kernels(pkg, oracle, known, torch_mod, name):
     ka = known["old_kernels"][name]
