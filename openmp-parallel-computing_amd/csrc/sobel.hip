@@ -120,14 +120,12 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // but the prefetch depth costs LDS (1 KiB per row and wave) instead of registers, so it can be deep: the plane kernel
 // moves only 2 B/px, a wave's row is consumed in ~550 cycles and the register-staged form cannot keep enough bytes
 // in flight at 3 waves per SIMD.  The last strip of a row is shifted left to end at the frame edge (all strips full).
-// AL = 1: rows start at multiples of 16 bytes (width % 16 == 0, aligned plane).  AL = 0: any width / base -- per row the DMA source
-// is the 16-byte-aligned address at or below the strip start and the lanes read LDS `a` bytes further (see issue_row).
-template <int D, int PROBE = 0, int SP = 2, int LP = 1, int AL = 1>
+template <int D, int PROBE = 0, int SP = 2, int LP = 1>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
     using namespace stream_core;
-    constexpr int SLOT = STRIP_PX + (AL ? 16 : 32);              // one strip row + the halo dword pair (AL) / the two 16-byte blocks
+    constexpr int SLOT = STRIP_PX + 16;                          // one strip row + the halo dword pair
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
     static_assert(3 * (D - 1) <= 60, "vmcnt is 6 bits");
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
@@ -176,45 +174,11 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     StateF2 st;
     st.clear();
 
-    // AL == 0 bookkeeping, per ring slot (wave-uniform): where in the slot the lanes' own 16 pixels start (q_off = a), and where
-    // the left / right neighbour pixel of the strip lies
-    uint32_t q_off[D], l_at[D], r_at[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) { q_off[k] = 0; l_at[k] = 0; r_at[k] = 0; }
-    // the bytes this launch may read: the band's rows plus its halo rows where they exist
-    const uint8_t *const lo = src - (zero_top ? 0 : w), *const hi = src + (size_t)(rows + (zero_bot ? 0 : 1)) * w;
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-
     auto issue_row = [&](int i, int slot) {
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
+        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        if (AL) {
-            const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
-            glds_row1k_halo<LP>(d, d + STRIP_PX, rowb, voff, hoff, slot);      // always exactly 2 vector-memory instructions
-            return;
-        }
-        // Slot image: [main 1024 B][block R 16 B][block L 16 B].  A = first byte of the strip in this row, a = A mod 16.
-        //  aligned-down mode (a > 0 and the block behind the strip lies inside the readable bytes): main = [A - a, A - a + 1024),
-        //    block R = the next 16 bytes (the strip's last a bytes, then its right neighbour); the strip's byte j sits at
-        //    slot + a + j, its left neighbour at slot + a - 1, its right neighbour at slot + a + 1024.  Block L is not needed.
-        //  direct mode (a == 0, or the first strip of the first / last strip of the last readable row: main or block R would leave the buffer):
-        //    main = [A, A + 1024) -- an unaligned DMA when a > 0 --, block R = 16 bytes that hold the right neighbour (moved
-        //    back when they would pass the end), block L = 16 bytes that hold the left neighbour (moved up at the very start).
-        const uint8_t *rowp = src + (ptrdiff_t)yy * w, *A = rowp + xw;
-        const uint32_t a = (uint32_t)(uintptr_t)A & 15u;
-        const bool down = a != 0 && A - a >= lo && A - a + STRIP_PX + 16 <= hi;      // (not at the very first / very last readable bytes)
-        const uint32_t ae = down ? a : 0u;
-        const uint8_t *base = A - ae;
-        const uint8_t *Rb = down ? base + STRIP_PX : (xw + STRIP_PX < w ? (A + STRIP_PX + 16 <= hi ? A + STRIP_PX : hi - 16) : base);
-        const uint8_t *Lb = (!down && xw > 0) ? (A - 16 >= lo ? A - 16 : lo) : base;
-        const uint8_t *rowb16 = rowp - 16;                           // offsets from here are >= 0 (never dereferenced itself)
-        q_off[slot] = uniform_u32(ae);
-        // (a strip at the frame's left / right edge has no such neighbour: any in-slot byte will do, the result column is masked)
-        l_at[slot] = uniform_u32(down ? ae - 1u : (xw > 0 ? (uint32_t)(STRIP_PX + 16) + (uint32_t)((A - 1) - Lb) : 0u));
-        r_at[slot] = uniform_u32(down ? (uint32_t)STRIP_PX + ae : (xw + STRIP_PX < w ? (uint32_t)STRIP_PX + (uint32_t)((A + STRIP_PX) - Rb) : 0u));
-        const uint32_t vo = lane16 + uniform_u32((uint32_t)(base - rowb16));
-        const uint32_t ho = lane == 0 ? uniform_u32((uint32_t)(Rb - rowb16)) : uniform_u32((uint32_t)(Lb - rowb16));
-        glds_row1k_blocks<LP>(d, d + STRIP_PX, uniform_ptr(rowb16), vo, ho, slot);   // always exactly 2 vector-memory instructions
+        glds_row1k_halo<LP>(d, d + STRIP_PX, rowb, voff, hoff, slot);      // always exactly 2 vector-memory instructions
     };
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) issue_row(i, i);
@@ -237,21 +201,12 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             wait_vm<0>(j % D);
         }
         const uint8_t *slotp = &ring[wave][j % D][0];
-        uint4 q;
-        uint2 hh;
-        if (AL) {
-            q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
-            hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
-        } else {
-            struct __attribute__((packed, aligned(1))) Quad { uint32_t x, y, z, w; };   // one ds_read_b128 at a byte address (replayed by the LDS when a != 0)
-            const Quad t = *reinterpret_cast<const Quad *>(slotp + q_off[j % D] + 16 * lane);
-            q = make_uint4(t.x, t.y, t.z, t.w);
-            hh = make_uint2((uint32_t)slotp[l_at[j % D]] << 24, (uint32_t)slotp[r_at[j % D]]);
-        }
+        const uint4 q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
+        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
         uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
         uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
-        if (lane == 0) ql = AL ? hh.x << lsh : hh.x;
-        if (lane == 63) qr = AL ? hh.y >> rsh : hh.y;
+        if (lane == 0) ql = hh.x << lsh;
+        if (lane == 63) qr = hh.y >> rsh;
         // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
         const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
         f32x2 G[10];
@@ -534,8 +489,6 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);  // probe: default-policy DMA loads
             else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #endif
-            else if (!aligned && GH_TUNE_INT("GH_SOBEL_DMA_BLOCKS", 1))      // rows not 16-byte aligned: aligned-down DMA + shifted LDS reads (0: unaligned DMA)
-                k_sobel_dma<3, 0, 2, 1, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);

@@ -365,23 +365,6 @@ __device__ __forceinline__ void glds_row1k_halo(uint32_t lds_slot, uint32_t lds_
     if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_GLDS_HALO GH_GLDS_OPS);     // default policy: probe only
     else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_HALO GH_GLDS_OPS);
 }
-// Rows that are not 16-byte aligned (frames whose width is not a multiple of 16): the same statement shape, but the second
-// instruction is a 16-byte-per-lane piece for lanes 0 and 1 -- two 16-byte BLOCKS (see k_sobel_dma, AL == 0): the main piece is
-// fetched from the 16-byte-aligned address at or below the strip start (an unaligned 16-B-per-lane piece costs the address unit
-// three 128-B lines per 16 lanes instead of two), lane 0's block is the one right behind it, lane 1's the one that holds the left
-// neighbour pixel when the strip start is aligned.  Still exactly 2 vector-memory instructions.
-template <int LP = 1>
-__device__ __forceinline__ void glds_row1k_blocks(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
-{
-    uint32_t keep;
-    uint64_t keepx;
-#define GH_BLOCKS "s_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, 3\n\t"        \
-                  "global_load_lds_dwordx4 %6, %3 nt ; gh_dma slot=%7\n\t"                      \
-                  "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-    if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_BLOCKS GH_GLDS_OPS);
-    else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_BLOCKS GH_GLDS_OPS);
-#undef GH_BLOCKS
-}
 #undef GH_PIECE
 #undef GH_GLDS_OPS
 #undef GH_GLDS_HALO

@@ -719,15 +719,13 @@ def test_many_passes(pkg, oracle, torch_mod, w, h, c):
 
 @pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2), (1025, 5), (1026, 67), (1027, 130), (1028, 3),
                                  (2049, 70), (3073, 65), (2037, 90), (16370, 24)])
-@pytest.mark.parametrize("dma_unaligned", ["blocks", "direct", "0"])
+@pytest.mark.parametrize("dma_unaligned", ["1", "0"])
 def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, dma_unaligned, monkeypatch):
     """Frame widths that are not a multiple of 16 (rows start at unaligned bytes).  Widths >= 1024: the LDS-DMA ring kernel
     (the right halo dword of a strip that ends within 3 bytes of the row end is fetched earlier and shifted: w % 1024 in 1..3);
     GH_SOBEL_DMA_UNALIGNED=0 or narrower frames: the register-staged strip kernel on the first w & ~15 columns with unaligned
     vector accesses + a per-pixel kernel for the rest (forced on for small frames here)."""
-    # "blocks" (default): aligned-down DMA + shifted LDS reads; "direct": DMA from the unaligned row address; "0": no DMA kernel
-    monkeypatch.setenv("GH_SOBEL_DMA_UNALIGNED", "0" if dma_unaligned == "0" else "1")
-    monkeypatch.setenv("GH_SOBEL_DMA_BLOCKS", "0" if dma_unaligned == "direct" else "1")
+    monkeypatch.setenv("GH_SOBEL_DMA_UNALIGNED", dma_unaligned)
     monkeypatch.setenv("GH_SOBEL_UNALIGNED_MIN_PX", "1")
     plane = oracle.frame_rand(w, h, 1, seed=w + h).reshape(h, w)
     want = oracle.sobel(plane)
