@@ -20,8 +20,9 @@ RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three st
 contract's bracket (barrier + synchronize on both sides, MAX over ranks):
     pipelined     a stream of frames in a ring of three buffers; the halo of frame k+2 travels while frame k runs as one
                   launch (`value`, as in round 1);
-    single_frame  ONE frame, strong-scaled: exchange || interior rows, then the first and last row (BASELINE configs[3]
-                  as written: the latency of one sharded frame);
+    single_frame  ONE frame, strong-scaled (BASELINE configs[3] as written: the latency of one sharded frame): the one-row
+                  exchange, then one launch over the shard (libgrayhip's default; its overlapped form -- exchange || interior
+                  rows, then first and last row -- measured slower at every shard size, csrc/comm.hip);
     end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory.
 Every kernel is the hand-written gfx950 code in libgrayhip.so, called through its C ABI; torch is only
 the allocator, the stream provider and the process group.
@@ -709,7 +710,7 @@ def main() -> int:
                     "host_enqueue_us_per_step": round(host * 1e6 / k_steps, 1), "steps": k_steps}, el
 
         forms = {}
-        # (b) ONE frame, strong-scaled: exchange || interior rows, then the first and last row
+        # (b) ONE frame, strong-scaled: the one-row exchange, then one launch over the shard
         forms["single_frame"], _ = run_form(single_impl, args.steps, "single_frame")
         # Sum of the edge plane over all ranks against the compiled reference's known answer (single-frame form, frame rand(seed=1))
         edge_sum_check = "skipped"

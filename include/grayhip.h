@@ -174,9 +174,11 @@ GH_API int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up
                                 const void *send_down, void *recv_down, size_t bytes, gh_stream_t stream);
 /* in-place sum of count u64 over all ranks (channel sums of old/parallel_avg_pixel.c on a sharded frame) */
 GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream);
-/* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  The exchange runs on
- * the communicator's side stream while the interior rows run on `stream`; the first and last row follow once the
- * halo has landed.  Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
+/* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default: the one-row
+ * exchange is enqueued on `stream`, then ONE launch covers the shard.  GH_SHARD_STEP_SERIAL=0: the exchange runs on the
+ * communicator's side stream while the interior rows run on `stream`; the first and last row follow once the halo has
+ * landed (pays two event hand-overs and two extra launches: slower for every shard size measured, comm.hip).
+ * Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
  *   fused: buf = interleaved RGB8/RGBA8 rows, the halo is one RGB row (the luma plane never exists in HBM)
  *   sobel: buf = luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,

@@ -210,13 +210,25 @@ int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t coun
 
 // ---- one pipeline step of a row shard ------------------------------------------------------------------------------
 // buf: (rows + 2) rows of `row_bytes`; rows 1..rows are the shard, rows 0 / rows+1 receive the neighbours' edge rows.
-// exchange (side stream) || interior rows (caller's stream) -> first and last row once the halo has landed.
+// Two forms: serial (exchange, then one launch) and overlapped (exchange on the side stream || interior rows on the caller's
+// stream -> first and last row once the halo has landed).
 template <typename Launch>
 static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */)
 {
     int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
     if (c->loopback) up = down = c->rank;      // a middle shard whose neighbours are itself: halo = its own edge rows
     if (up < 0 && down < 0) return launch(0, rows, 1, 1);
+    // Serial form (default; GH_SHARD_STEP_SERIAL=0 selects the overlapped form below): the exchange is enqueued on the caller's
+    // stream in front of ONE launch over the whole shard -- no side stream, no events, no one-row launches.  The exchange is then
+    // not hidden, but it moves one row (~11 us in the loopback rehearsal), while the overlapped form pays two cross-queue event
+    // hand-overs and two extra launches: 41 vs 58 us per step for the 2048-row shard of an 8-GPU split, 61 vs 65 us at 4096 rows,
+    // 110 vs 116 us at 8192 rows (tools/r2_call_o.sh; the pipelined form, which prefetches halos two frames ahead: 38 us).
+    if (GH_TUNE_INT("GH_SHARD_STEP_SERIAL", 1)) {
+        if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
+                                          row_bytes, s))
+            return rc;
+        return launch(0, rows, up < 0, down < 0);
+    }
     // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
     GH_HIP_TRY(hipEventRecord(c->ready, s));
     GH_HIP_TRY(hipStreamWaitEvent(c->side, c->ready, 0));

@@ -476,10 +476,13 @@ def test_native_comm_self_exchange(pkg, native_comm, torch_mod):
 
 
 @pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130)])
-def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h):
-    """The C++ sharded step (exchange on the side stream || interior rows, then first / last row) as a middle shard whose
+@pytest.mark.parametrize("serial", ["1", "0"])
+def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, serial, monkeypatch):
+    """The C++ sharded step -- serial form (exchange on the caller's stream, then one launch over the shard: the default) and
+    overlapped form (exchange on the side stream || interior rows, then first / last row) -- as a middle shard whose
     neighbours are itself: the halo rows must become copies of the shard's own edge rows, i.e. the result equals the
     oracle on the frame padded by replicating its first and last row."""
+    monkeypatch.setenv("GH_SHARD_STEP_SERIAL", serial)
     t = torch_mod
     img = oracle.frame_rand(w, h, 3, seed=w * 7 + h)
     padded = np.concatenate([img[:1], img, img[-1:]], axis=0)
