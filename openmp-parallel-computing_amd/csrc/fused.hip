@@ -275,13 +275,17 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 // the only loads younger than row i's are those of rows i+1 .. i+D-1 (4 instructions each); output stores in between
 // only make the count conservative.  The last strip of a row is shifted left to end at the frame edge (all strips are
 // full; the overlap is recomputed and stored twice with identical bytes), so no lane of a DMA piece is ever masked.
-template <int MODE, int D, int SP, int CH = 3>
+// UNAL != 0 (frames whose rows or base are not 16-byte aligned): every row's pieces start at the 16-byte aligned address at or
+// before the strip (far enough before it to carry the left halo pixel) and land dword-shifted in LDS; UNAL = 2 re-aligns the
+// lane's bytes with v_alignbyte_b32 -- see k_sobel_dma in sobel.hip for the scheme and the counters behind it.
+template <int MODE, int D, int SP, int CH = 3, int UNAL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK)
 void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
                  int zero_bot)
 {
     using namespace stream_core;
-    constexpr int SLOT = STRIP_PX * CH + 16;                      // one strip row + the halo dword pair
+    constexpr int PRE = UNAL ? 16 : 0;                            // UNAL: room in front of the lane grid (pieces land up to 16 bytes early)
+    constexpr int SLOT = UNAL ? 16 + STRIP_PX * CH + 32 : STRIP_PX * CH + 16;   // one strip row + the halo dword pair / pre-area + 32-byte tail
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
     constexpr int NLD = CH + 1;                                   // DMA pieces per row: CH x 1 KiB + the halo dword
     static_assert((NLD + 1) * (D - 1) <= 60, "vmcnt is 6 bits");
@@ -331,13 +335,32 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     StateF2 st;
     st.clear();
 
-    auto issue_row = [&](int i, int slot) {
+    const bool has_right = xw + STRIP_PX < w;                    // (wave-uniform) a pixel right of the strip exists
+    auto strip_row = [&](int i) {                                // first byte of the strip in band row i (wave-uniform)
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
-        const uint8_t *rowb = uniform_ptr(rgb + (ptrdiff_t)yy * w * CH);
+        return uniform_ptr(rgb + ((ptrdiff_t)yy * w + xw) * CH);
+    };
+    auto issue_row = [&](int i, int slot) {
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         // always exactly NLD vector-memory instructions, one statement
-        if (CH == 3) glds_row3k_halo<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
-        else glds_row4k_halo(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
+        if (UNAL) {
+            constexpr uint32_t ROWB = STRIP_PX * CH;
+            const uint8_t *A = strip_row(i);
+            const uint32_t a = (uint32_t)(uintptr_t)A & 15u;
+            const uint32_t ap = (a < (uint32_t)CH && xw > 0) ? a + 16u : a;        // the pieces start a' bytes before the strip: the left pixel is in them
+            // tail blocks (relative to the first piece): the block behind the pieces holds the strip's last a' bytes (a' >= 1) or the
+            // right halo pixel; the second one is fetched only where it holds bytes of the strip (a' > 16) or of that pixel --
+            // every block fetched contains a byte of the frame, so no access leaves the frame's pages
+            const uint32_t t0 = (ap == 0u && !has_right) ? ROWB - 16u : ROWB;
+            const uint32_t t1 = (ap > 16u || (has_right && ap + (uint32_t)CH > 16u)) ? ROWB + 16u : t0;
+            const uint32_t dm = uniform_u32(dst + PRE + (a & 3u) - ap);
+            if (CH == 3) glds_row3k_tail(dm, dm + ROWB, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
+            else glds_row4k_tail(dm, dm + ROWB, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
+        } else {
+            const uint8_t *rowb = strip_row(i) - (ptrdiff_t)xw * CH;
+            if (CH == 3) glds_row3k_halo<(SP >= 100 ? SP / 100 - 1 : 1)>(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
+            else glds_row4k_halo(dst, dst + STRIP_PX * CH, rowb, voff, hoff, slot);
+        }
     };
     // nrows >= 3 > D - 1 for D <= 3; for deeper rings the prologue may run past a very short band: clamp_row keeps it readable
 #pragma unroll
@@ -359,12 +382,31 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
             wait_vm<0>(j % D);
         }
         const uint8_t *slotp = &ring[wave][j % D][0];
-        const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + 16 * CH * lane);
+        const uint4 *sr = reinterpret_cast<const uint4 *>(slotp + PRE + 16 * CH * lane);
         uint32_t wv[4 * CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) { const uint4 u = sr[k]; wv[4 * k] = u.x; wv[4 * k + 1] = u.y; wv[4 * k + 2] = u.z; wv[4 * k + 3] = u.w; }
-        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
-        const uint32_t hw = lane == 0 ? (CH == 3 ? ((hh.x << lsh) >> 8) : hh.x) : (hh.y >> rsh);
+        uint32_t hw;
+        if (UNAL) {
+            // the dword in front of the lane grid and the two behind it (wave-uniform addresses)
+            const uint32_t fl = *reinterpret_cast<const uint32_t *>(slotp + PRE - 4);
+            const uint2 fr = *reinterpret_cast<const uint2 *>(slotp + PRE + STRIP_PX * CH);
+            uint32_t hl = fl, hr = fr.x;
+            if (UNAL == 2) {                                         // the strip starts at byte sh of the lane grid
+                const uint32_t sh = (uint32_t)(uintptr_t)strip_row(i) & 3u;
+                uint32_t nx = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+                if (lane == 63) nx = fr.x;
+                hl = __builtin_amdgcn_alignbyte(wv[0], fl, sh);
+                hr = __builtin_amdgcn_alignbyte(fr.y, fr.x, sh);
+#pragma unroll
+                for (int k = 0; k < 4 * CH - 1; ++k) wv[k] = __builtin_amdgcn_alignbyte(wv[k + 1], wv[k], sh);
+                wv[4 * CH - 1] = __builtin_amdgcn_alignbyte(nx, wv[4 * CH - 1], sh);
+            }
+            hw = lane == 0 ? (CH == 3 ? hl >> 8 : hl) : hr;
+        } else {
+            const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX * CH);
+            hw = lane == 0 ? (CH == 3 ? ((hh.x << lsh) >> 8) : hh.x) : (hh.y >> rsh);
+        }
         uint4 out;
         if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
         else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
@@ -430,16 +472,16 @@ __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__res
 struct DmaLaunch {
     const uint8_t *rgb; uint8_t *edge; int width, rows, groups_x; BandPlan plan; int zt, zb, channels, mode; unsigned grid; size_t pad; hipStream_t s;
 };
-template <int D, int SP>
+template <int D, int SP, int UNAL = 0>
 void launch_fused_dma(const DmaLaunch &L)
 {
     const unsigned b = stream_core::BLOCK;
     if (L.channels == 4) {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
     } else {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP, 3><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP, 3, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
     }
 }
 
@@ -530,7 +572,14 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             if (pad_kb < 0) pad_kb = 0;
             const size_t pad = (size_t)pad_kb * 1024;
             const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s};
-            if (sp == 2) {                      // production: nontemporal output stores
+            // frames with unaligned rows: GH_FUSED_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_fused_dma, UNAL), 1 = pieces from
+            // the strip's own unaligned address, 0 = register-staged strips + column tail
+            const int unal = aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 2) < 2 || dma == 4 ? 0
+                             : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
+            if (sp == 2 && unal) {
+                if (dma == 2) { if (unal == 1) launch_fused_dma<2, 2, 1>(L); else launch_fused_dma<2, 2, 2>(L); }
+                else { if (unal == 1) launch_fused_dma<3, 2, 1>(L); else launch_fused_dma<3, 2, 2>(L); }
+            } else if (sp == 2) {               // production: nontemporal output stores
                 if (dma == 2) launch_fused_dma<2, 2>(L);
                 else if (dma == 4) launch_fused_dma<4, 2>(L);
                 else launch_fused_dma<3, 2>(L);

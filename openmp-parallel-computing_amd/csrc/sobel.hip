@@ -120,12 +120,24 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // but the prefetch depth costs LDS (1 KiB per row and wave) instead of registers, so it can be deep: the plane kernel
 // moves only 2 B/px, a wave's row is consumed in ~550 cycles and the register-staged form cannot keep enough bytes
 // in flight at 3 waves per SIMD.  The last strip of a row is shifted left to end at the frame edge (all strips full).
-template <int D, int PROBE = 0, int SP = 2, int LP = 1>
+//
+// UNAL (frames whose row pitch or base address is not a multiple of 16): a global_load_lds_dwordx4 whose lanes' 16 bytes are
+// not 16-byte aligned costs the texture-address / L1 path four times the tag accesses of an aligned one (rocprofv3
+// TCP_TOTAL_CACHE_ACCESSES 3.4x, TA_BUSY 1.9x on a 16370-wide plane; HBM traffic unchanged) and the kernel 7-9 % of its time.
+// UNAL != 0 therefore starts every row's piece at the 16-byte aligned address G = A - a' at or before the strip's first byte A
+// (a' = A mod 16, or 16 when that is 0 and a left neighbour exists, so the piece always carries the left halo pixel) and
+// fetches the 16 or 32 bytes behind the piece with the row's two-lane instruction.  An LDS-DMA destination needs only DWORD
+// alignment (measured: tools/glds_align_test.hip -- byte offsets are rounded down), so the piece is landed 4 * (a' / 4) bytes
+// early and the strip's first pixel sits at byte s = A mod 4 of the slot's lane grid: every ds_read stays naturally aligned.
+// UNAL = 1: s is 0 for every row (pitch and base multiples of 4): nothing else changes.  UNAL = 2: the lane's 16 pixels and
+// its two neighbours are re-aligned in registers, six v_alignbyte_b32 with the row's (wave-uniform) s.
+template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
     using namespace stream_core;
-    constexpr int SLOT = STRIP_PX + 16;                          // one strip row + the halo dword pair
+    constexpr int PRE = UNAL ? 16 : 0;                           // UNAL: 16 bytes in front of the lane grid (the piece may land up to 16 early)
+    constexpr int SLOT = UNAL ? 16 + STRIP_PX + 32 : STRIP_PX + 16;   // one strip row + the halo dword pair / + pre-area and 32-byte tail
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
     static_assert(3 * (D - 1) <= 60, "vmcnt is 6 bits");
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
@@ -174,11 +186,27 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     StateF2 st;
     st.clear();
 
-    auto issue_row = [&](int i, int slot) {
+    const bool has_right = xw + STRIP_PX < w;                    // (wave-uniform) a pixel right of the strip exists
+    auto strip_row = [&](int i) {                                // first byte of the strip in band row i (wave-uniform)
         const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
-        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        return uniform_ptr(src + (ptrdiff_t)yy * w + xw);
+    };
+    auto issue_row = [&](int i, int slot) {
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        glds_row1k_halo<LP>(d, d + STRIP_PX, rowb, voff, hoff, slot);      // always exactly 2 vector-memory instructions
+        if (UNAL) {
+            const uint8_t *A = strip_row(i);
+            const uint32_t a = (uint32_t)(uintptr_t)A & 15u;
+            const uint32_t ap = (a == 0u && xw > 0) ? 16u : a;
+            // tail blocks (relative to G): the one behind the piece holds the strip's last a' pixels (a' >= 1) or the right halo
+            // pixel (a' = 0); neither -> the piece's last block again.  The second one is fetched only where it holds the right
+            // halo pixel (a' = 16).  Every block fetched thus contains a byte of the frame: no access leaves its pages.
+            const uint32_t t0 = (ap == 0u && !has_right) ? (uint32_t)STRIP_PX - 16u : (uint32_t)STRIP_PX;
+            const uint32_t t1 = (ap == 16u && has_right) ? (uint32_t)STRIP_PX + 16u : t0;
+            const uint32_t dm = uniform_u32(d + PRE + (a & 3u) - ap);
+            glds_row1k_tail(dm, dm + STRIP_PX, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
+        } else {
+            glds_row1k_halo<LP>(d, d + STRIP_PX, strip_row(i) - xw, voff, hoff, slot);      // always exactly 2 vector-memory instructions
+        }
     };
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) issue_row(i, i);
@@ -201,12 +229,23 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             wait_vm<0>(j % D);
         }
         const uint8_t *slotp = &ring[wave][j % D][0];
-        const uint4 q = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
-        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
+        uint4 q = *reinterpret_cast<const uint4 *>(slotp + PRE + 16 * lane);
+        uint2 hh;
+        if (UNAL) hh = make_uint2(*reinterpret_cast<const uint32_t *>(slotp + PRE - 4), *reinterpret_cast<const uint32_t *>(slotp + PRE + STRIP_PX));
+        else hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
         uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
         uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
-        if (lane == 0) ql = hh.x << lsh;
-        if (lane == 63) qr = hh.y >> rsh;
+        if (lane == 0) ql = UNAL ? hh.x : hh.x << lsh;
+        if (lane == 63) qr = UNAL ? hh.y : hh.y >> rsh;
+        if (UNAL == 2) {                                             // the strip starts at byte s of the lane grid
+            const uint32_t sh = (uint32_t)(uintptr_t)strip_row(i) & 3u;
+            ql = __builtin_amdgcn_alignbyte(q.x, ql, sh);
+            q.x = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+            q.y = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+            q.z = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+            q.w = __builtin_amdgcn_alignbyte(qr, q.w, sh);
+            qr >>= 8u * sh;
+        }
         // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
         const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
         f32x2 G[10];
@@ -472,7 +511,17 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             // reach HBM.  With the output rotating over six planes it is the other way round (sc1 62.6 %, plain 60.7 %,
             // nt 66.8 %; tools/ab_fused.py --out-ring 6), and nt performs the same in both settings.
             const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
-            if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            // frames with unaligned rows: GH_SOBEL_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_sobel_dma, UNAL), 1 = pieces
+            // from the strip's own unaligned address, 0 = register-staged strips + column tail (further down)
+            const int unal = aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? 0 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
+            if (unal && sp == 0) {
+                if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            } else if (unal) {
+                if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                else k_sobel_dma<3, 0, 2, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            }
+            else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #ifdef GH_ENABLE_PROBES
             else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW

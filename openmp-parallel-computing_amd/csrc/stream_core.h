@@ -327,9 +327,13 @@ __device__ __forceinline__ bool row_readable(int yy, int rows, int zero_top, int
 // against other volatile asm, so a row is always exactly `pieces + 1` vector-memory instructions in program order -- the
 // quantity the waits are counted in.  (Every lane is active where rows are issued: the strip kernels branch wave-uniformly.)
 #define GH_GLDS_HEAD  "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-#define GH_GLDS_HALO  "s_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, 3\n\t"        \
-                      "global_load_lds_dword %6, %3 ; gh_dma slot=%7\n\t"                         \
+#define GH_GLDS_HALO_OP(OPC) "s_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, 3\n\t"  \
+                      OPC " %6, %3 ; gh_dma slot=%7\n\t"                                           \
                       "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+#define GH_GLDS_HALO  GH_GLDS_HALO_OP("global_load_lds_dword")
+// rows of frames whose pitch or base is not a multiple of 16 (see k_sobel_dma, UNAL): the piece starts at a 16-byte aligned
+// address at or before the strip, and the two lanes of the last instruction fetch the one or two 16-byte blocks behind it
+#define GH_GLDS_TAIL  GH_GLDS_HALO_OP("global_load_lds_dwordx4")
 #define GH_GLDS_OPS   : "=&s"(keep), "=&s"(keepx)                                                    \
                       : "v"(voff), "s"(rowb), "s"(lds_slot), "s"(lds_halo), "v"(hoff), "i"(slot)    \
                       : "memory"
@@ -365,9 +369,32 @@ __device__ __forceinline__ void glds_row1k_halo(uint32_t lds_slot, uint32_t lds_
     if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_GLDS_HALO GH_GLDS_OPS);     // default policy: probe only
     else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_HALO GH_GLDS_OPS);
 }
+// the same rows with a 32-byte tail instead of the halo dword pair (operand names as above: lds_halo = where the tail lands,
+// hoff = the two lanes' offsets of the tail blocks)
+__device__ __forceinline__ void glds_row1k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_TAIL GH_GLDS_OPS);
+}
+__device__ __forceinline__ void glds_row3k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_PIECE(" offset:1024", " nt") GH_PIECE(" offset:2048", " nt") GH_GLDS_TAIL GH_GLDS_OPS);
+}
+__device__ __forceinline__ void glds_row4k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_PIECE(" offset:1024", " nt") GH_PIECE(" offset:2048", " nt") GH_PIECE(" offset:3072", " nt")
+                 GH_GLDS_TAIL GH_GLDS_OPS);
+}
 #undef GH_PIECE
 #undef GH_GLDS_OPS
+#undef GH_GLDS_TAIL
 #undef GH_GLDS_HALO
+#undef GH_GLDS_HALO_OP
 #undef GH_GLDS_HEAD
 
 // Band plan of a strip kernel launch: level l has n[l] bands of R[l] rows starting at row y[l]; the last level runs to the

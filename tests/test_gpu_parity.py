@@ -575,12 +575,15 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
 
 
 @pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3),
-                                   (1025, 5, 3), (1025, 67, 4), (1026, 130, 3), (3073, 65, 3), (2037, 90, 3), (16370, 24, 3)])
-@pytest.mark.parametrize("dma_unaligned", ["1", "0"])
+                                   (1025, 5, 3), (1025, 67, 4), (1026, 130, 3), (3073, 65, 3), (2037, 90, 3), (16370, 24, 3),
+                                   (2052, 40, 3), (1044, 9, 3), (16380, 24, 3), (5000, 33, 3), (1039, 66, 4), (1028, 35, 4), (1030, 7, 3)])
+@pytest.mark.parametrize("dma_unaligned", ["2", "1", "0"])
 def test_fused_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, c, dma_unaligned, monkeypatch):
-    """The fused C entry point takes any width.  Widths >= 1024: the LDS-DMA ring kernel itself (DMA pieces need no alignment on
-    the global side; GH_FUSED_DMA_UNALIGNED=0: register-staged unaligned strips + per-pixel column tail instead); narrower
-    frames: strips + tail or the per-pixel kernel alone; unaligned buffer bases; whole frames and bands with real RGB halo rows."""
+    """The fused C entry point takes any width.  Widths >= 1024: the LDS-DMA ring kernel itself -- GH_FUSED_DMA_UNALIGNED=2
+    (default): every row's pieces start at the 16-byte aligned address before the strip and land dword-shifted in LDS (rows
+    that are multiples of 4 bytes: nothing else; other rows: v_alignbyte re-alignment); =1: pieces from the strip's own
+    unaligned address; =0: register-staged unaligned strips + per-pixel column tail instead; narrower frames: strips + tail or
+    the per-pixel kernel alone; unaligned buffer bases; whole frames and bands with real RGB halo rows."""
     monkeypatch.setenv("GH_FUSED_DMA_UNALIGNED", dma_unaligned)
     img = oracle.frame_rand(w, h, c, seed=w * 3 + h)
     d = dev(torch_mod, img)
@@ -721,13 +724,15 @@ def test_many_passes(pkg, oracle, torch_mod, w, h, c):
 
 
 @pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2), (1025, 5), (1026, 67), (1027, 130), (1028, 3),
-                                 (2049, 70), (3073, 65), (2037, 90), (16370, 24)])
-@pytest.mark.parametrize("dma_unaligned", ["1", "0"])
+                                 (2049, 70), (3073, 65), (2037, 90), (16370, 24), (2052, 40), (1044, 9), (16380, 24), (5000, 33), (1039, 66)])
+@pytest.mark.parametrize("dma_unaligned", ["2", "1", "0"])
 def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, dma_unaligned, monkeypatch):
-    """Frame widths that are not a multiple of 16 (rows start at unaligned bytes).  Widths >= 1024: the LDS-DMA ring kernel
-    (the right halo dword of a strip that ends within 3 bytes of the row end is fetched earlier and shifted: w % 1024 in 1..3);
-    GH_SOBEL_DMA_UNALIGNED=0 or narrower frames: the register-staged strip kernel on the first w & ~15 columns with unaligned
-    vector accesses + a per-pixel kernel for the rest (forced on for small frames here)."""
+    """Frame widths that are not a multiple of 16 (rows start at unaligned bytes).  Widths >= 1024: the LDS-DMA ring kernel --
+    GH_SOBEL_DMA_UNALIGNED=2 (default): every row's piece starts at the 16-byte aligned address at or before the strip and
+    lands dword-shifted in LDS (widths that are multiples of 4: nothing else; other widths: v_alignbyte re-alignment);
+    =1: pieces from the strip's own unaligned address (the right halo dword of a strip that ends within 3 bytes of the row end
+    is fetched earlier and shifted: w % 1024 in 1..3); =0 or narrower frames: the register-staged strip kernel on the first
+    w & ~15 columns with unaligned vector accesses + a per-pixel kernel for the rest (forced on for small frames here)."""
     monkeypatch.setenv("GH_SOBEL_DMA_UNALIGNED", dma_unaligned)
     monkeypatch.setenv("GH_SOBEL_UNALIGNED_MIN_PX", "1")
     plane = oracle.frame_rand(w, h, 1, seed=w + h).reshape(h, w)

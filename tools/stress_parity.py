@@ -18,7 +18,7 @@ KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": 
              {"GH_FUSED_DMA_R": "16", "GH_SOBEL_R": "16"}, {"GH_FUSED_DMA_R": "32", "GH_SOBEL_R": "32"}, {"GH_FUSED_DMA_R": "7", "GH_SOBEL_R": "5"},
              {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"}, {"GH_FUSED_DMA_ORDER": "4", "GH_SOBEL_ORDER": "4"},
              {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"},
-             {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}]
+             {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"}]
 
 
 def run(secs: float, seed: int, verbose: bool = True):
