@@ -222,6 +222,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         const int i = ch * CHK + j;
         if (KIND == 0 && i >= nrows) return true;                    // past the band: so is every later step -- the wave is done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
+        if (PROBE == 3 || PROBE == 4) __builtin_amdgcn_s_barrier();  // probe: the workgroup's four strips advance row by row together (every wave must be live)
         if (KIND != 0 || i + D - 1 < nrows) {
             issue_row(i + D - 1, (j + D - 1) % D);
             if (KIND == 2) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
         G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
         uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
-        if (PROBE == 2) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
+        if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
         if (KIND != 0 || i >= 2) {                                  // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
             if (x == 0) out.x &= 0xffffff00u;
@@ -535,6 +536,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             }
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
             else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
+            else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);   // probe: row-synchronous workgroup
+            else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);   // the same without arithmetic
             else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);  // probe: default-policy DMA loads
             else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
 #endif

@@ -326,6 +326,25 @@ def test_host_shim_chunked_pipeline(pkg, oracle, w, h, c, passes, monkeypatch):
     assert np.array_equal(buf, oracle.gray_inplace(img, 0))
 
 
+@pytest.mark.parametrize("w,h", [(2048, 1100), (1999, 1237), (4096, 1025), (16384, 200), (1024, 2049)])
+def test_host_shim_chunked_sobel_edge(pkg, oracle, w, h, monkeypatch):
+    """Large planes go through sobel_edge's host entry point in row chunks (upload of chunk k+1 overlaps the filter on the rows
+    chunk k completed and their download); forced here on small planes: 1 Mpixel chunks (at least 64 rows), no size threshold.
+    dst's border must stay untouched exactly as with the reference (sobel.c:11-12)."""
+    monkeypatch.setenv("GH_HOST_CHUNK_MPX", "1")
+    monkeypatch.setenv("GH_HOST_PIPELINE_MIN_MB", "0")
+    plane = oracle.frame_rand(w, h, 1, seed=w + h).reshape(h, w)
+    want = oracle.sobel(plane)
+    dst = np.full((h, w), 0xA5, dtype=np.uint8)
+    pkg.sobel_edge(plane, dst, w, h)
+    assert np.array_equal(dst[1:-1, 1:-1], want[1:-1, 1:-1])
+    assert (dst[0] == 0xA5).all() and (dst[-1] == 0xA5).all() and (dst[:, 0] == 0xA5).all() and (dst[:, -1] == 0xA5).all()
+    monkeypatch.setenv("GH_HOST_PIPELINE_MIN_MB", "1000000")      # and the single-copy path gives the same bytes
+    dst2 = np.full((h, w), 0xA5, dtype=np.uint8)
+    pkg.sobel_edge(plane, dst2, w, h)
+    assert np.array_equal(dst, dst2)
+
+
 @pytest.mark.parametrize("name", ["rand1_1024x1024", "rand1_1021x517"])
 def test_old_kernels(pkg, oracle, known, torch_mod, name):
     ka = known["old_kernels"][name]
