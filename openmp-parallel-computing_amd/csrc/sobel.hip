@@ -287,6 +287,146 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 }
 
 #ifdef GH_ENABLE_PROBES
+// ---- access-pattern probe: wider strips -- a wave owns PIECES KiB of every row (PIECES LDS-DMA pieces + the halo dword per row step) ----
+// The fused kernel (3 KiB of RGB per wave and row) sits closer to its linear-copy ceiling than the plane Sobel (1 KiB): is it the
+// size of the contiguous piece a wave reads per row?  Same ring, waits and stores as k_sobel_dma's no-arithmetic skeleton
+// (GH_SOBEL_DMA=33), strips PIECES times as wide, a quarter / half as many waves.  Output = a copy of the input rows (not a Sobel result).
+template <int PIECES, int D, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_wide_strip_probe(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
+                                                                        int groups_x, stream_core::BandPlan plan)
+{
+    using namespace stream_core;
+    constexpr int SW = STRIP_PX * PIECES;
+    constexpr int SLOT = SW + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WPB][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    if (gy_i < 0) return;
+    const int xw = (gx_i * WPB + wave) * SW;
+    if (xw + SW > w) return;
+    const int R = plan.R[0], y0 = gy_i * R;
+    const int nrows = min(R, rows - y0) + 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + SW >= w)) hoff = 0;
+    auto issue = [&](int i, int slot) {
+        int yy = y0 - 1 + i; yy = yy < 0 ? 0 : (yy >= rows ? rows - 1 : yy);
+        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        const uint32_t dh = d + SW;
+        uint32_t keep; uint64_t keepx;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)          // one instruction per statement; volatile asm keeps their order
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff + (uint32_t)p * STRIP_PX), "s"(rowb), "s"(d + (uint32_t)p * STRIP_PX) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 3\n\tglobal_load_lds_dword %4, %2\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keepx) : "s"(rowb), "s"(dh), "v"(hoff) : "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue(i, i);
+#pragma unroll 1
+    for (int i0 = 0; i0 < nrows; i0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int i = i0 + j;
+            if (i >= nrows) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + D - 1 < nrows) {
+                issue(i + D - 1, (j + D - 1) % D);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PIECES + 1) * (D - 1)) : "memory");      // conservative: stores in between not counted
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const uint8_t *slotp = &ring[wave][j][0];
+            const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + SW);
+            if (i >= 2) {
+                const int y = y0 + i - 2;
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p) {
+                    uint4 q = *reinterpret_cast<const uint4 *>(slotp + p * STRIP_PX + 16 * lane);
+                    q.x ^= hh.x & 0u; q.w ^= hh.y & 0u;
+                    store_strip_p<2>(dst + (size_t)y * w + xw + p * STRIP_PX, lane, q);
+                }
+            } else {
+                asm volatile("" ::"v"(hh.x), "v"(hh.y));
+            }
+        }
+    }
+}
+
+// ---- access-pattern probe: one loader wave per workgroup -- wave 0 brings the workgroup's whole 4 KiB of a row in (four pieces +
+// one halo dword, back to back), one s_barrier per row hands it to the four waves, each of which reads and stores its own 1 KiB.
+// Separates "4 KiB per row issued by ONE wave" (the wide-strip probe's gain) from "4 KiB stored by one wave".  Output = input rows.
+template <int D>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_loader_probe(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
+                                                                    int groups_x, stream_core::BandPlan plan)
+{
+    using namespace stream_core;
+    constexpr int SW = STRIP_PX * WAVES_PER_BLOCK;
+    constexpr int SLOT = SW + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    if (gy_i < 0) return;
+    const int xw = gx_i * SW;                      // workgroup-uniform
+    if (xw + SW > w) return;
+    const int R = plan.R[0], y0 = gy_i * R;
+    const int nrows = min(R, rows - y0) + 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[0][0];
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + SW >= w)) hoff = 0;
+    auto issue = [&](int i, int slot) {            // wave 0 only
+        int yy = y0 - 1 + i; yy = yy < 0 ? 0 : (yy >= rows ? rows - 1 : yy);
+        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        const uint32_t dh = d + SW;
+        uint32_t keep; uint64_t keepx;
+#pragma unroll
+        for (int p = 0; p < WAVES_PER_BLOCK; ++p)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff + (uint32_t)p * STRIP_PX), "s"(rowb), "s"(d + (uint32_t)p * STRIP_PX) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 3\n\tglobal_load_lds_dword %4, %2\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keepx) : "s"(rowb), "s"(dh), "v"(hoff) : "memory");
+    };
+    // rows 0 .. D-2 are in flight when the loop starts; at step i the loader has issued rows up to i + D - 2
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) issue(i, i);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < nrows; i0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int i = i0 + j;
+            if (i >= nrows) return;
+            // row i has landed: younger than its five instructions are rows i+1 .. i+D-2 (5 each) and wave 0's own stores (uncounted: conservative)
+            if (wave == 0) {
+                if (i + D - 2 < nrows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (D - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of the previous row's slot are done
+            __builtin_amdgcn_s_barrier();
+            if (wave == 0 && i + D - 1 < nrows) issue(i + D - 1, (j + D - 1) % D);     // into the slot every wave read in step i - 1
+            const uint8_t *slotp = &ring[j][0];
+            const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + SW);
+            if (i >= 2) {
+                const int y = y0 + i - 2;
+                uint4 q = *reinterpret_cast<const uint4 *>(slotp + wave * STRIP_PX + 16 * lane);
+                q.x ^= hh.x & 0u; q.w ^= hh.y & 0u;
+                store_strip_p<2>(dst + (size_t)y * w + xw + wave * STRIP_PX, lane, q);
+            } else {
+                asm volatile("" ::"v"(hh.x), "v"(hh.y));
+            }
+        }
+    }
+}
+
 // ---- access-pattern probe: "band march" -- a wave owns RW rows and marches ALONG them, 1 KiB per step -------------------------
 // The strip kernels above walk DOWN a 1 KiB-wide strip; their no-arithmetic skeleton runs as fast as the real kernel, i.e. the
 // traversal, not the arithmetic, is the limit.  This probe moves the same bytes (RW + 2 input rows in, RW rows out per wave and
@@ -533,6 +673,24 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 else if (rw == 8) k_march_probe<8><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
                 else if (rw == 14) k_march_probe<14><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
                 else k_march_probe<2><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+            }
+            else if (dma >= 200 && dma < 1800 && (dma % 100 >= 2 && dma % 100 <= 4) && width % (dma >= 1700 ? 4096 : 1024 * (dma / 100) * (dma >= 1600 ? 1 : (dma >= 800 ? 2 : 4))) == 0 && rows % R == 0) {
+                // wide-strip probe: dma = 100 * KiB per wave and row + ring depth (8 and 16 KiB: two / one wave per workgroup)
+                const int pieces = dma >= 1700 ? 1 : dma / 100, wpb = pieces >= 16 ? 1 : (pieces >= 8 ? 2 : 4), gxw = width / (1024 * pieces * wpb);
+                stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), pw.bands, gxw);
+                const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
+                if (dma == 203) k_wide_strip_probe<2, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 202) k_wide_strip_probe<2, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 403) k_wide_strip_probe<4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 402) k_wide_strip_probe<4, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 803) k_wide_strip_probe<8, 3, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 802) k_wide_strip_probe<8, 2, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 1703) k_loader_probe<3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);      // 17xx: the loader-wave probe (4 KiB per workgroup and row)
+                else if (dma == 1704) k_loader_probe<4><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 1603) k_wide_strip_probe<16, 3, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 1602) k_wide_strip_probe<16, 2, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else GH_REQUIRE(false, "wide-strip probe: unknown size / depth");
             }
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
             else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
