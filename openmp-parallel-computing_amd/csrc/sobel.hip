@@ -291,7 +291,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // The fused kernel (3 KiB of RGB per wave and row) sits closer to its linear-copy ceiling than the plane Sobel (1 KiB): is it the
 // size of the contiguous piece a wave reads per row?  Same ring, waits and stores as k_sobel_dma's no-arithmetic skeleton
 // (GH_SOBEL_DMA=33), strips PIECES times as wide, a quarter / half as many waves.  Output = a copy of the input rows (not a Sobel result).
-template <int PIECES, int D, int WPB = 4>
+// OUTDIV = 3: the fused kernel's shape -- PIECES KiB in, PIECES / 3 KiB out per wave and row (run it on a "plane" three times as wide).
+template <int PIECES, int D, int WPB = 4, int OUTDIV = 1>
 __global__ __launch_bounds__(64 * WPB) void k_wide_strip_probe(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                         int groups_x, stream_core::BandPlan plan)
 {
@@ -345,10 +346,15 @@ __global__ __launch_bounds__(64 * WPB) void k_wide_strip_probe(const uint8_t *__
             if (i >= 2) {
                 const int y = y0 + i - 2;
 #pragma unroll
-                for (int p = 0; p < PIECES; ++p) {
-                    uint4 q = *reinterpret_cast<const uint4 *>(slotp + p * STRIP_PX + 16 * lane);
+                for (int p = 0; p < PIECES / OUTDIV; ++p) {
+                    uint4 q = *reinterpret_cast<const uint4 *>(slotp + p * OUTDIV * STRIP_PX + 16 * lane);
+#pragma unroll
+                    for (int o = 1; o < OUTDIV; ++o) {
+                        const uint4 t = *reinterpret_cast<const uint4 *>(slotp + (p * OUTDIV + o) * STRIP_PX + 16 * lane);
+                        q.x ^= t.x; q.y ^= t.y; q.z ^= t.z; q.w ^= t.w;
+                    }
                     q.x ^= hh.x & 0u; q.w ^= hh.y & 0u;
-                    store_strip_p<2>(dst + (size_t)y * w + xw + p * STRIP_PX, lane, q);
+                    store_strip_p<2>(dst + (size_t)y * (w / OUTDIV) + xw / OUTDIV + p * STRIP_PX, lane, q);
                 }
             } else {
                 asm volatile("" ::"v"(hh.x), "v"(hh.y));
@@ -691,6 +697,21 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 else if (dma == 1603) k_wide_strip_probe<16, 3, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
                 else if (dma == 1602) k_wide_strip_probe<16, 2, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
                 else GH_REQUIRE(false, "wide-strip probe: unknown size / depth");
+            }
+            else if (dma >= 30000 && dma < 40000 && width % 12288 == 0 && rows % R == 0) {
+                // 3:1 wide-strip probe on a plane of 3 x 16384 bytes per row: dma = 30000 + 100 * KiB read per wave and row + ring depth
+                const int pieces = (dma - 30000) / 100, depth = dma % 100, wpb = pieces >= 12 ? (depth == 3 ? 1 : 2) : (pieces >= 6 ? (depth == 3 ? 2 : 4) : 4);
+                const int gxw = width / (1024 * pieces * wpb);
+                stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 6), pw.bands, gxw);
+                const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
+                if (dma == 30302) k_wide_strip_probe<3, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 30303) k_wide_strip_probe<3, 3, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 30602) k_wide_strip_probe<6, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 30603) k_wide_strip_probe<6, 3, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 31202) k_wide_strip_probe<12, 2, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else if (dma == 31203) k_wide_strip_probe<12, 3, 1, 3><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+                else GH_REQUIRE(false, "3:1 wide-strip probe: unknown size / depth");
             }
             else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
             else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
