@@ -663,6 +663,43 @@ def test_streamed_row_blocks_equal_whole_frame(pkg, oracle):
     assert np.array_equal(part, want[y0:y1])
 
 
+@pytest.mark.parametrize("w", [1024, 1025, 1027, 1030, 1036, 1039, 1040, 2051, 2064, 3073])
+def test_every_base_alignment_through_the_ring_kernels(pkg, oracle, torch_mod, w):
+    """The aligned-down LDS-DMA rows (UNAL variants) take a different branch per (address mod 16) of a strip's first byte: piece
+    start, LDS landing offset, which tail blocks are fetched, the byte re-alignment.  Every input base offset 0..15 (and two output
+    offsets), for the plane Sobel and the fused kernel (RGB8 and RGBA8), whole frames and bands with real halo rows; the bytes
+    around the output must stay untouched."""
+    t = torch_mod
+    h = 6
+    plane = oracle.frame_rand(w, h, 1, seed=w).reshape(h, w)
+    want_s = oracle.sobel(plane)
+    imgs = {c: oracle.frame_rand(w, h, c, seed=w + c) for c in (3, 4)}
+    want_f = {c: oracle.sobel(oracle.gray_to_plane(imgs[c], 0)) for c in (3, 4)}
+    for so in range(16):
+        for do in (0, 7):
+            raw_in = t.zeros(h * w + 48, dtype=t.uint8, device="cuda")
+            raw_out = t.full((h * w + 48,), 0x5A, dtype=t.uint8, device="cuda")
+            src = raw_in[so:so + h * w].view(h, w)
+            dst = raw_out[do:do + h * w].view(h, w)
+            src.copy_(dev(t, plane))
+            pkg.hostapi.sobel(src, out=dst)
+            assert np.array_equal(dst.cpu().numpy(), want_s), ("sobel", so, do)
+            assert (raw_out[:do] == 0x5A).all() and (raw_out[do + h * w:] == 0x5A).all(), ("sobel guard", so, do)
+            band = t.full((h - 2, w), 0x5A, dtype=t.uint8, device="cuda")
+            pkg.hostapi.sobel_rows(src, band, h - 2, False, False)
+            assert np.array_equal(band.cpu().numpy(), want_s[1:h - 1]), ("sobel band", so, do)
+            for c in (3, 4):
+                raw_in = t.zeros(h * w * c + 48, dtype=t.uint8, device="cuda")
+                raw_out.fill_(0x5A)
+                src3 = raw_in[so:so + h * w * c].view(h, w, c)
+                src3.copy_(dev(t, imgs[c]))
+                pkg.hostapi.gray_sobel_fused(src3, 0, out=dst)
+                assert np.array_equal(dst.cpu().numpy(), want_f[c]), ("fused", c, so, do)
+                assert (raw_out[:do] == 0x5A).all() and (raw_out[do + h * w:] == 0x5A).all(), ("fused guard", c, so, do)
+                pkg.hostapi.gray_sobel_fused_rows(src3, band, h - 2, 0, False, False)
+                assert np.array_equal(band.cpu().numpy(), want_f[c][1:h - 1]), ("fused band", c, so, do)
+
+
 def test_random_geometry_sweep(pkg, oracle, torch_mod):
     """Seeded sweep over frame geometries around the kernels' internal boundaries (1024-px strips, 64/32/16-row bands, the
     shifted last strip, one- and two-row frames) for the plane Sobel, the fused RGB8 / RGBA8 kernels and their band forms."""
