@@ -64,7 +64,7 @@ oracle:
 	$(MAKE) -C oracle all
 
 # device assembly of the LDS-DMA kernels with the library's own flags (tests/test_isa_vmcnt.py analyses it)
-isa: build_isa/sobel.s build_isa/fused.s
+isa: build_isa/sobel.s build_isa/fused.s build_isa/conv3x3.s
 build_isa/%.s: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p build_isa
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S $< -o $@ 2>/dev/null || $(HIPCC) $(HIPFLAGS) --cuda-device-only -S $< -o $@

@@ -6,6 +6,8 @@
 // division (truncation toward zero).  The frame is treated as a byte plane of width 3*w: output
 // byte xb depends on input bytes xb-3, xb, xb+3 of three rows.  Bound: HBM, 3 R + 3 W bytes per pixel.
 //
+//   k_conv3x3_dma     default: the strip walk below with the rows brought HBM -> LDS by LDS-DMA (the ring of k_sobel_dma), any
+//                     row length >= 1024 bytes and any alignment; same arithmetic and exactness conditions as k_conv3x3_stream.
 //   k_conv3x3_stream  strip streaming (same walk as the Sobel kernels, stream_core.h): a wave owns 1024 bytes
 //                     of every row, taps and sums in packed f32 on exact integers, two bytes per VALU op
 //                     ("pair layout": byte m paired with byte m+8), rolling partial sums so that every input
@@ -156,6 +158,163 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
     }
 }
 
+// ---- LDS-DMA ring form (any row length >= 1024 bytes, any alignment) -----------------------------------------------------------
+// The same row ring as k_sobel_dma (sobel.hip; waits counted by hand, checked on the generated code by tests/test_isa_vmcnt.py):
+// a wave's 1 KiB of each row of the 3w-byte plane goes HBM -> LDS directly, D rows deep; rows of frames whose pitch or base is not
+// a multiple of 16 start at the aligned address before the strip and land dword-shifted (UNAL, see k_sobel_dma).  The last strip of
+// a row is shifted left to end at the row's last byte, so every strip is full.  Rows outside the frame and bytes outside a row are
+// zeros (the reference pre-pads its array).
+template <int D, int UNAL>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int wb, int h,
+                                                                   int groups_x, stream_core::BandPlan plan, TapsF t)
+{
+    using namespace stream_core;
+    constexpr int PRE = UNAL ? 16 : 0;
+    constexpr int SLOT = UNAL ? 16 + STRIP_PX + 32 : STRIP_PX + 16;
+    constexpr int CHK = (D % 2 == 0) ? D : 2 * D;
+    static_assert(3 * (D - 1) <= 60, "vmcnt is 6 bits");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * STRIP_PX;        // first BYTE of this wave's strip
+    if (xw >= wb) return;
+    if (xw + STRIP_PX > wb) xw = wb - STRIP_PX;
+    if (gy_i < 0) return;
+    const int R = plan.R[0], y0 = gy_i * R;
+    const int nrows = min(R, h - y0) + 2;
+    const int nch = (nrows + CHK - 1) / CHK;
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero (see the exactness note above)
+    const bool has_right = xw + STRIP_PX < wb;
+    // bytes of the row left / right of the strip that the taps can reach: 3 each, fewer where the row ends first (a shifted last
+    // strip may start at byte 1 or 2, the strip before it may end 1 or 2 bytes before the row does); what lies beyond is zero
+    const int nl = min(3, xw), nr = min(3, wb - xw - STRIP_PX);
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    // aligned frames: halo dwords = the 4 bytes before / after the strip (16-byte aligned rows: always inside the row when they exist)
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + STRIP_PX);
+    if ((lane == 0 && xw == 0) || (lane != 0 && !has_right)) hoff = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+
+    const f32x2 inv2 = {t.inv, t.inv}, hinv2 = {t.half_inv, t.half_inv};
+    f32x2 kk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kk[i] = f32x2{t.k[i], t.k[i]};
+    f32x2 a1[8], a0[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a1[k] = f32x2{0.f, 0.f}; a0[k] = f32x2{0.f, 0.f}; }
+
+    auto strip_row = [&](int i) {                                // first byte of the strip in band row i, clamped into the frame (wave-uniform)
+        int yy = y0 - 1 + i;
+        yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        return uniform_ptr(src + (ptrdiff_t)yy * wb + xw);
+    };
+    auto issue_row = [&](int i, int slot) {
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        if (UNAL) {
+            const uint8_t *A = strip_row(i);
+            const uint32_t a = (uint32_t)(uintptr_t)A & 15u;
+            const uint32_t ap = a < (uint32_t)nl ? a + 16u : a;                    // the piece carries the nl bytes left of the strip
+            // tail blocks: fetched only where they hold bytes of the strip or of its nr right neighbours -- every block read contains a byte of the row
+            const uint32_t t0 = (ap == 0u && !has_right) ? (uint32_t)STRIP_PX - 16u : (uint32_t)STRIP_PX;
+            const uint32_t t1 = (ap > 16u || (nr > 0 && ap + (uint32_t)nr > 16u)) ? (uint32_t)STRIP_PX + 16u : t0;
+            const uint32_t dm = uniform_u32(d + PRE + (a & 3u) - ap);
+            glds_row1k_tail(dm, dm + STRIP_PX, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
+        } else {
+            glds_row1k_halo<1>(d, d + STRIP_PX, strip_row(i) - xw, voff, hoff, slot);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue_row(i, i);
+
+    // row step in the three statically different forms of k_sobel_dma: 0 generic, 1 transition, 2 steady (exact count 3 (D-1))
+    auto row_step = [&](auto kind_c, int ch, int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int i = ch * CHK + j;
+        if (KIND == 0 && i >= nrows) return true;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KIND != 0 || i + D - 1 < nrows) {
+            issue_row(i + D - 1, (j + D - 1) % D);
+            if (KIND == 2) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
+        } else {
+            wait_vm<0>(j % D);
+        }
+        const uint8_t *slotp = &ring[wave][j % D][0];
+        uint4 q = *reinterpret_cast<const uint4 *>(slotp + PRE + 16 * lane);
+        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+        if (UNAL) {
+            const uint32_t fl = *reinterpret_cast<const uint32_t *>(slotp + PRE - 4);
+            const uint2 fr = *reinterpret_cast<const uint2 *>(slotp + PRE + STRIP_PX);
+            if (lane == 0) ql = fl;
+            if (lane == 63) qr = fr.x;
+            if (UNAL == 2) {                                         // the strip starts at byte sh of the lane grid
+                const uint32_t sh = (uint32_t)(uintptr_t)strip_row(i) & 3u;
+                uint32_t qr2 = __builtin_amdgcn_update_dpp(0u, q.y, 0x130, 0xf, 0xf, false);
+                if (lane == 63) qr2 = fr.y;
+                ql = __builtin_amdgcn_alignbyte(q.x, ql, sh);
+                q.x = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+                q.y = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+                q.z = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+                q.w = __builtin_amdgcn_alignbyte(qr, q.w, sh);
+                qr = __builtin_amdgcn_alignbyte(qr2, qr, sh);
+            }
+        } else {
+            const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
+            if (lane == 0) ql = hh.x;
+            if (lane == 63) qr = hh.y;
+        }
+        // zeros outside the row and outside the frame: ql = bytes x-4 .. x-1 of which the last nl are in the row, qr = bytes x+16 .. x+19
+        // of which the first nr are
+        if (lane == 0 && nl < 3) ql = nl == 0 ? 0u : ql & (~0u << (8 * (4 - nl)));
+        if (lane == 63 && nr < 3) qr = nr <= 0 ? 0u : qr & (~0u >> (8 * (4 - nr)));
+        const int yin = y0 - 1 + i;
+        if (yin < 0 || yin >= h) { q = make_uint4(0, 0, 0, 0); ql = 0; qr = 0; }
+        // p[-3..18] as floats; pair layout G[m] = (p[m-3], p[m+5]), m = 0..13
+        const uint32_t wv[6] = {ql, q.x, q.y, q.z, q.w, qr};                   // wv[0] bytes = p[-4..-1]
+        f32x2 G[14];
+#pragma unroll
+        for (int m = 0; m < 14; ++m) {
+            const int b0 = m - 3 + 4, b1 = m + 5 + 4;
+            G[m] = f32x2{opaque((float)gh_byte(wv[b0 >> 2], b0 & 3)), opaque((float)gh_byte(wv[b1 >> 2], b1 & 3))};
+        }
+        uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 L = G[k], M = G[k + 3], Rr = G[k + 6];
+            const f32x2 h0 = __builtin_elementwise_fma(Rr, kk[2], __builtin_elementwise_fma(M, kk[1], L * kk[0]));
+            const f32x2 h1 = __builtin_elementwise_fma(Rr, kk[5], __builtin_elementwise_fma(M, kk[4], L * kk[3]));
+            const f32x2 h2 = __builtin_elementwise_fma(Rr, kk[8], __builtin_elementwise_fma(M, kk[7], L * kk[6]));
+            const f32x2 acc = a1[k] + h2;
+            a1[k] = a0[k] + h1;
+            a0[k] = h0;
+            const f32x2 qf = __builtin_elementwise_fma(acc, inv2, hinv2);
+            r[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(qf.x, k & 3, r[k >> 2]);
+            r[2 + (k >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(qf.y, k & 3, r[2 + (k >> 2)]);
+        }
+        if (KIND != 0 || i >= 2)                                     // y = y0 + i - 2 < h by construction of nrows
+            store_strip_p<2>(dst + (size_t)(y0 + i - 2) * wb + xw, lane, make_uint4(r[0], r[1], r[2], r[3]));
+        return false;
+    };
+    auto chunk = [&](auto kind_c, int ch) {
+#pragma unroll
+        for (int j = 0; j < CHK; ++j)
+            if (row_step(kind_c, ch, j)) return true;
+        return false;
+    };
+    const int n_full = (nrows - D + 1) / CHK;
+    if (chunk(std::integral_constant<int, 0>{}, 0)) return;
+    int ch = 1;
+    if (n_full >= 2) {
+        chunk(std::integral_constant<int, 1>{}, 1);
+#pragma unroll 1
+        for (ch = 2; ch < n_full; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
+    }
+#pragma unroll 1
+    for (; ch < nch; ++ch)
+        if (chunk(std::integral_constant<int, 0>{}, ch)) return;
+}
+
 }  // namespace
 
 extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height, const int32_t kernel[9], int32_t norm,
@@ -174,14 +333,39 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
     // trunc(acc / norm) == trunc(-acc / -norm): normalise to a positive divisor
     const int sgn = norm < 0 ? -1 : 1;
     const long long wb = (long long)width * 3;
-    const bool fast = (wb % 16 == 0) && gh_aligned16(src) && gh_aligned16(dst) && (long long)sgn * norm <= 4096 && ksum * 255 < (1ll << 24) &&
-                      !getenv("GH_CONV_IMPL");
-    if (fast) {
-        TapsF t;
-        for (int i = 0; i < 9; ++i) t.k[i] = (float)(sgn * kernel[i]);
+    const bool exact = (long long)sgn * norm <= 4096 && ksum * 255 < (1ll << 24) && !getenv("GH_CONV_IMPL");     // conditions of the f32 forms
+    const bool aligned = (wb % 16 == 0) && gh_aligned16(src) && gh_aligned16(dst);
+    TapsF t;
+    for (int i = 0; i < 9; ++i) t.k[i] = (float)(sgn * kernel[i]);
+    {
         const float n = (float)(sgn * norm);
         t.inv = 1.0f / n;
         t.half_inv = 0.5f / n;
+    }
+    // LDS-DMA ring kernel: any row of 1024 bytes and more, any alignment (GH_CONV_DMA=0: the register-staged strips, aligned frames only)
+    if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_TUNE_INT("GH_CONV_DMA", 1)) {
+        const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
+        const int groups_x = (int)((wb + span - 1) / span);
+        int R = GH_TUNE_INT("GH_CONV_R", 0);
+        if (R <= 0) {
+            const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
+            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+        }
+        stream_core::BandPlan plan = stream_core::make_band_plan(height, R, -1, 0, -1, 0);
+        // pairs-per-XCD dispatch order (8): 0.290 ms against 0.293 (band-per-XCD) / 0.294 (plain) on 16384^2, ahead on 16368 / 16370 too
+        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x);
+        const long long nb = stream_core::plan_grid(plan, groups_x);
+        GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
+        const int unal = aligned ? 0 : ((wb % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
+        const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
+        if (unal == 0) k_conv3x3_dma<3, 0><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        else if (unal == 1) k_conv3x3_dma<3, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        else k_conv3x3_dma<3, 2><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+    const bool fast = exact && aligned;
+    if (fast) {
         // band height: 64 rows whenever that still gives every CU two workgroups (the same rule as the Sobel kernels:
         // 64-row bands measured 5-10 % faster than 32 on MI355X), else 32, else 16
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;

@@ -368,6 +368,32 @@ def test_conv3x3_signed_kernel_and_small_frames(pkg, oracle, torch_mod):
             assert np.array_equal(pkg.hostapi.conv3x3(d, k, norm).cpu().numpy(), oracle.conv3x3(img, k, norm)), (w, h, k)
 
 
+@pytest.mark.parametrize("w,h", [(342, 7), (343, 70), (344, 5), (350, 130), (1024, 67), (1365, 9), (1366, 33), (2731, 66), (5461, 20), (5464, 3), (683, 1), (700, 2)])
+def test_conv3x3_ring_kernel_any_width_and_alignment(pkg, oracle, torch_mod, w, h, monkeypatch):
+    """Rows of 1024 bytes and more (3 w >= 1024) run the LDS-DMA ring kernel k_conv3x3_dma whatever the width and the base
+    alignment (aligned frames: plain pieces; rows that are multiples of 4 bytes: dword-shifted landing; others: + byte
+    re-alignment); checked against the oracle, against the register-staged strips where those apply, for several kernels
+    (signed taps, norm > 1) and input offsets 0..15; the bytes around the output must stay untouched."""
+    t = torch_mod
+    img = oracle.frame_rand(w, h, 3, seed=w * 7 + h)
+    n = h * w * 3
+    for k, norm in (([1, 2, 1, 2, 4, 2, 1, 2, 1], 16), ([0, -1, 0, -1, 5, -1, 0, -1, 0], 1), ([-1, -2, -1, 0, 0, 0, 1, 2, 1], 3), ([3, 1, 4, 1, 5, 9, 2, 6, 5], 36)):
+        want = oracle.conv3x3(img, k, norm)
+        for so in ((0, 1, 2, 3, 4, 7, 8, 12, 13, 15) if k[0] == 1 else (0, 5)):
+            raw_in = t.zeros(n + 48, dtype=t.uint8, device="cuda")
+            raw_out = t.full((n + 48,), 0x5A, dtype=t.uint8, device="cuda")
+            src = raw_in[so:so + n].view(h, w, 3)
+            do = (so * 5) % 16
+            dst = raw_out[do:do + n].view(h, w, 3)
+            src.copy_(dev(t, img))
+            pkg.hostapi.conv3x3(src, k, norm, out=dst)
+            assert np.array_equal(dst.cpu().numpy(), want), (k, norm, so)
+            assert (raw_out[:do] == 0x5A).all() and (raw_out[do + n:] == 0x5A).all(), ("guard", so)
+        monkeypatch.setenv("GH_CONV_DMA", "0")            # register-staged strips (aligned frames) / per-pixel kernel
+        assert np.array_equal(pkg.hostapi.conv3x3(dev(t, img), k, norm).cpu().numpy(), want), (k, norm, "no dma")
+        monkeypatch.delenv("GH_CONV_DMA")
+
+
 def test_gray_of_plane_moves_13_levels(pkg, known, torch_mod):
     v = torch_mod.arange(256, dtype=torch_mod.uint8, device="cuda").repeat(5)
     out = pkg.hostapi.gray_of_plane(v, 0)[:256].cpu().numpy()

@@ -1,14 +1,14 @@
 """Pins the hand-counted `s_waitcnt vmcnt(N)` of the LDS-DMA ring kernels on the GENERATED gfx950 code (no GPU needed:
 hipcc cross-compiles here).
 
-k_fused_dma / k_sobel_dma bring rows HBM -> LDS with inline-asm `global_load_lds_*` instructions, which hipcc does not
+k_fused_dma / k_sobel_dma / k_conv3x3_dma bring rows HBM -> LDS with inline-asm `global_load_lds_*` instructions, which hipcc does not
 count; the kernels wait with their own `s_waitcnt vmcnt(N)` (stream_core.h).  vmcnt retires in order, so a wait for the
 row in ring slot S is correct iff, on EVERY path, at least N vector-memory instructions (LDS-DMA pieces of younger rows,
 output stores) are issued between the last DMA into slot S and the wait.  If the compiler ever sank an output store below
 the wait, dropped one, or the source miscounted, N would be too large: rare, timing-dependent corrupt rows.
 
 The asm statements print markers into the assembly (`; gh_dma slot=S` on each DMA instruction, `; gh_wait slot=S` on each
-wait).  This test compiles the two sources to device assembly with the library's own flags (`make isa`) and, for every
+wait).  This test compiles the three sources to device assembly with the library's own flags (`make isa`) and, for every
 shipped k_*_dma instantiation, walks FORWARD over every feasible path of the generated code keeping the list of the
 youngest vector-memory operations: at a `vmcnt(N)` wait for slot S no DMA into S may be among the N youngest.  A negative
 control mutates the code (N + 1; an output store sunk below the wait) and must be caught.  Finally the shipped
@@ -232,13 +232,14 @@ def device_asm():
         pytest.skip("hipcc not available")
     p = subprocess.run(["make", "isa"], cwd=ROOT, capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    return {k: open(os.path.join(ROOT, "build_isa", k + ".s")).read() for k in ("sobel", "fused")}
+    return {k: open(os.path.join(ROOT, "build_isa", k + ".s")).read() for k in ("sobel", "fused", "conv3x3")}
 
 
 def dma_functions(device_asm):
     fns = {}
     fns.update(parse_functions(device_asm["sobel"], "k_sobel_dma"))
     fns.update(parse_functions(device_asm["fused"], "k_fused_dma"))
+    fns.update(parse_functions(device_asm["conv3x3"], "k_conv3x3_dma"))
     return fns
 
 
@@ -252,7 +253,7 @@ def test_every_counted_wait_is_covered_on_every_path(device_asm):
         assert not failures, f"{name}:\n" + "\n".join(failures[:5])
         # the counts are the ones the source derives: A pieces per row (+1 output store per row in steady state), D - 1 rows
         t = template_ints(name)
-        if "k_sobel_dma" in name:
+        if "k_sobel_dma" in name or "k_conv3x3_dma" in name:
             d, a = t[0], 2
         else:
             d, a = t[1], t[3] + 1
@@ -301,7 +302,7 @@ def test_shipped_library_has_the_same_skeleton(device_asm, tmp_path):
         for line in dis.splitlines():
             m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
             if m:
-                cur = shipped.setdefault(m.group(1), []) if ("k_sobel_dma" in m.group(1) or "k_fused_dma" in m.group(1)) else None
+                cur = shipped.setdefault(m.group(1), []) if any(k in m.group(1) for k in ("k_sobel_dma", "k_fused_dma", "k_conv3x3_dma")) else None
                 continue
             if cur is not None and line.strip():
                 cur.append(Ins(line.split("//")[0].strip()))
