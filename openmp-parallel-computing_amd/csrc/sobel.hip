@@ -286,6 +286,139 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
+// ---- two strips per wave (aligned frames, width >= 2048): a wave owns 2 KiB of every row -----------------------------------------
+// The no-arithmetic skeletons run faster the more contiguous bytes ONE wave reads and writes per row (1 KiB:
+// 67-69 %, 2 KiB: 68-69 %, 4 KiB: 72 % of 8 TB/s).  The rolling Sobel state is 64 VGPRs per 1,024 columns, so two strips per wave
+// is what fits in 256 registers: the same row step run on two neighbouring 1 KiB strips out of one ring slot (two DMA pieces + the
+// halo dword per row, two stores), half as many waves, the per-row scalar work shared.  Between the two strips the neighbour
+// pixels come from the other strip's registers (v_readlane), not from LDS.
+// REG = 1 ("regular bands"): every band has exactly nrows = R + 2 input rows and nrows is a multiple of the unroll CHK (the host
+// checks rows % R == 0 and (R + 2) % CHK == 0: R = 64 or 16 with D = 3).  Then which steps issue a row and which store is known
+// per unrolled step -- first chunk: steps 0, 1 store nothing; last chunk: the last D - 1 steps issue nothing -- and the band runs
+// without a single data-dependent branch.  That is what keeps this kernel inside 256 registers at ring depth 3: the generic form's
+// early exits cost 70 more (allocated as AGPR spills in the tail, but they halve the residency of the whole kernel).
+template <int D, int LB = 1, int REG = 0>
+__global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
+                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
+{
+    using namespace stream_core;
+    constexpr int SW = 2 * STRIP_PX;
+    constexpr int SLOT = SW + 16;
+    constexpr int CHK = (D % 2 == 0) ? D : 2 * D;
+    static_assert(5 * (D - 1) <= 60, "vmcnt is 6 bits");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * SW;
+    if (xw >= w) return;
+    if (xw + SW > w) xw = w - SW;                                // last pair of strips: shifted left to end at the frame edge
+    if (gy_i < 0) return;
+    const int R = plan.R[0], y0 = gy_i * R;
+    const int nrows = min(R, rows - y0) + 2;
+    const int nch = (nrows + CHK - 1) / CHK;
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    const f32x2 half2 = half2_reg();
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + SW >= w)) hoff = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+
+    StateF2 st0, st1;
+    st0.clear();
+    st1.clear();
+
+    auto issue_row = [&](int i, int slot) {
+        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        glds_row2k_halo(d, d + SW, rowb, voff, hoff, slot);          // always exactly 3 vector-memory instructions
+    };
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue_row(i, i);
+
+    // row step in the statically different forms of k_sobel_dma (0 generic, 1 transition, 2 steady) plus, for regular bands, 3 = first
+    // chunk and 4 = last chunk; per row 3 DMA instructions and 2 stores: the generic, transition and first forms count the DMA
+    // instructions of the D-1 younger rows (3 each), the steady and last forms also their stores: 5 (D-1)
+    auto row_step = [&](auto kind_c, int ch, int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int i = ch * CHK + j;
+        if (KIND == 0 && i >= nrows) return true;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool issue = KIND == 0 ? i + D - 1 < nrows : (KIND == 4 ? j + D - 1 < CHK : true);     // (j is a constant in the unrolled chunk)
+        if (issue) {
+            issue_row(i + D - 1, (j + D - 1) % D);
+            if (KIND == 2 || KIND == 4) wait_vm<5 * (D - 1)>(j % D); else wait_vm<3 * (D - 1)>(j % D);
+        } else {
+            wait_vm<0>(j % D);
+        }
+        const uint8_t *slotp = &ring[wave][j % D][0];
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(slotp + STRIP_PX + 16 * lane);
+        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + SW);
+        const int y = y0 + i - 2;
+        const bool zero_row = (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
+        auto strip = [&](auto sub_c, StateF2 &st, const uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
+            constexpr int SUB = decltype(sub_c)::value;
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            if (lane == 0) ql = left_of_lane0;
+            if (lane == 63) qr = right_of_lane63;
+            const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
+            f32x2 G[10];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+            G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
+            G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
+            uint4 out = (j & 1) ? rowf2<1, 1>(st, G, half2) : rowf2<0, 1>(st, G, half2);
+            if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {       // y < rows by construction of nrows
+                const int x = xw + SUB * STRIP_PX + 16 * lane;
+                if (SUB == 0 && x == 0) out.x &= 0xffffff00u;
+                if (SUB == 1 && x + 15 == w - 1) out.w &= 0x00ffffffu;
+                if (zero_row) out = make_uint4(0, 0, 0, 0);
+                store_strip_p<2>(dst + (size_t)y * w + xw + SUB * STRIP_PX, lane, out);
+            }
+        };
+        // the pixel right of strip 0 is strip 1's first (lane 0, byte 0 of q1.x), the pixel left of strip 1 strip 0's last (lane 63, byte 3 of q0.w)
+        const uint32_t first_of_1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.x);
+        const uint32_t last_of_0 = (uint32_t)__builtin_amdgcn_readlane((int)q0.w, 63);
+        // (scheduling barriers: without them the compiler interleaves the two strips and the row steps and needs 326 registers)
+        __builtin_amdgcn_sched_barrier(0);
+        strip(std::integral_constant<int, 0>{}, st0, q0, hh.x, first_of_1);
+        __builtin_amdgcn_sched_barrier(0);
+        strip(std::integral_constant<int, 1>{}, st1, q1, last_of_0, hh.y);
+        __builtin_amdgcn_sched_barrier(0);
+        return false;
+    };
+    auto chunk = [&](auto kind_c, int ch) {
+#pragma unroll
+        for (int j = 0; j < CHK; ++j)
+            if (row_step(kind_c, ch, j)) return true;
+        return false;
+    };
+    if (REG) {                                       // nch >= 3 chunks, all of them full
+        static_assert(!REG || D == 3, "the exact count of the second chunk's first step needs the two steps before it to have stored");
+        chunk(std::integral_constant<int, 3>{}, 0);
+#pragma unroll 1
+        for (int ch = 1; ch < nch - 1; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
+        chunk(std::integral_constant<int, 4>{}, nch - 1);
+        return;
+    }
+    const int n_full = (nrows - D + 1) / CHK;
+    if (chunk(std::integral_constant<int, 0>{}, 0)) return;
+    int ch = 1;
+    if (n_full >= 2) {
+        chunk(std::integral_constant<int, 1>{}, 1);
+#pragma unroll 1
+        for (ch = 2; ch < n_full; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
+    }
+#pragma unroll 1
+    for (; ch < nch; ++ch)
+        if (chunk(std::integral_constant<int, 0>{}, ch)) return;
+}
+
 #ifdef GH_ENABLE_PROBES
 // ---- access-pattern probe: wider strips -- a wave owns PIECES KiB of every row (PIECES LDS-DMA pieces + the halo dword per row step) ----
 // The fused kernel (3 KiB of RGB per wave and row) sits closer to its linear-copy ceiling than the plane Sobel (1 KiB): is it the
@@ -660,6 +793,33 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
             // frames with unaligned rows: GH_SOBEL_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_sobel_dma, UNAL), 1 = pieces
             // from the strip's own unaligned address, 0 = register-staged strips + column tail (further down)
+            // Two strips per wave (k_sobel_dma2, regular-band form): aligned frames whose rows split into whole bands of 64 or 16 rows
+            // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/r2_call_ai.sh,
+            // r2_call_aj.sh): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
+            // 0.0521 / 0.0262 vs 0.0309 / 0.0166 vs 0.0185, 8192^2 0.0270 vs 0.0288, 7680 x 4352 0.0230 vs 0.0246; narrow or small
+            // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
+            // 64-row bands when they still give every CU a workgroup, else 16.  GH_SOBEL_NS = 1: never, 2: whenever the geometry allows.
+            const int ns_knob = GH_TUNE_INT("GH_SOBEL_NS", 0);
+            if (aligned && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
+                const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
+                const int R2 = r_env > 0 ? r_env : ((rows % 64 == 0 && (long long)gx2 * (rows / 64) >= GH_NUM_CU) ? 64 : 16);
+                const bool regular = R2 >= 16 && rows % R2 == 0 && (R2 + 2) % 6 == 0;           // every band: R2 + 2 input rows = whole chunks of 6
+                if (regular && (ns_knob == 2 || (pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU))) {
+                    stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
+                    p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2);
+                    const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
+#ifdef GH_ENABLE_PROBES
+                    const int nsd = GH_TUNE_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: DESIGN.md)
+                    if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else
+#endif
+                    k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    GH_LAUNCH_CHECK();
+                    return GH_OK;
+                }
+            }
             const int unal = aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? 0 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
             if (unal && sp == 0) {
                 if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);

@@ -369,6 +369,13 @@ __device__ __forceinline__ void glds_row1k_halo(uint32_t lds_slot, uint32_t lds_
     if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_GLDS_HALO GH_GLDS_OPS);     // default policy: probe only
     else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_HALO GH_GLDS_OPS);
 }
+// 2 KiB row (two neighbouring u8 plane strips owned by one wave: k_sobel_dma2)
+__device__ __forceinline__ void glds_row2k_halo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_PIECE(" offset:1024", " nt") GH_GLDS_HALO GH_GLDS_OPS);
+}
 // the same rows with a 32-byte tail instead of the halo dword pair (operand names as above: lds_halo = where the tail lands,
 // hoff = the two lanes' offsets of the tail blocks)
 __device__ __forceinline__ void glds_row1k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)

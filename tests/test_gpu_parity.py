@@ -689,6 +689,42 @@ def test_streamed_row_blocks_equal_whole_frame(pkg, oracle):
     assert np.array_equal(part, want[y0:y1])
 
 
+@pytest.mark.parametrize("w,h", [(2048, 16), (2048, 64), (2064, 32), (4096, 128), (4112, 48), (6144, 64), (8192, 192), (8208, 16), (16384, 64), (16384, 80),
+                                 (10240, 256), (16400, 128)])
+@pytest.mark.parametrize("band_rows", ["", "16", "64"])
+def test_sobel_two_strips_per_wave(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
+    """k_sobel_dma2: a wave owns two neighbouring 1 KiB strips of every row (aligned frames whose rows split into whole bands of 64 or
+    16 rows; the launcher picks it by itself for large frames).  Forced here (GH_SOBEL_NS=2) on small ones: widths that are and are
+    not multiples of 2048 (the last pair of strips is shifted left), one and several bands, whole frames and bands with real halo
+    rows; GH_SOBEL_NS=1 (one strip per wave) must give the same bytes."""
+    if band_rows and h % int(band_rows):
+        pytest.skip("rows do not split into whole bands of that height")
+    monkeypatch.setenv("GH_SOBEL_NS", "2")
+    if band_rows:
+        monkeypatch.setenv("GH_SOBEL_R", band_rows)
+    t = torch_mod
+    plane = oracle.frame_rand(w, h + 2, 1, seed=w + h).reshape(h + 2, w)
+    d = dev(t, plane)
+    want = oracle.sobel(plane[1:h + 1])
+    got = pkg.hostapi.sobel(d[1:h + 1])
+    assert np.array_equal(got.cpu().numpy(), want)
+    want_band = oracle.sobel(plane)[1:h + 1]                       # rows 1 .. h of the taller frame: real halo rows above and below
+    for top, bot in ((False, False), (True, False), (False, True)):
+        out = t.empty((h, w), dtype=t.uint8, device="cuda")
+        pkg.hostapi.sobel_rows(d, out, h, top, bot)
+        ref = want_band.copy()
+        if top:
+            ref[0] = 0
+        if bot:
+            ref[-1] = 0
+        if top or bot:
+            ref = oracle.sobel(plane[1 if top else 0:(h + 1) if bot else (h + 2)])
+            ref = ref[(0 if top else 1):(0 if top else 1) + h]
+        assert np.array_equal(out.cpu().numpy(), ref), (top, bot)
+    monkeypatch.setenv("GH_SOBEL_NS", "1")
+    assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1]).cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("w", [1024, 1025, 1027, 1030, 1036, 1039, 1040, 2051, 2064, 3073])
 def test_every_base_alignment_through_the_ring_kernels(pkg, oracle, torch_mod, w):
     """The aligned-down LDS-DMA rows (UNAL variants) take a different branch per (address mod 16) of a strip's first byte: piece

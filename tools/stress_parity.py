@@ -18,7 +18,8 @@ KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": 
              {"GH_FUSED_DMA_R": "16", "GH_SOBEL_R": "16"}, {"GH_FUSED_DMA_R": "32", "GH_SOBEL_R": "32"}, {"GH_FUSED_DMA_R": "7", "GH_SOBEL_R": "5"},
              {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"}, {"GH_FUSED_DMA_ORDER": "4", "GH_SOBEL_ORDER": "4"},
              {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"},
-             {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"}]
+             {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"},
+             {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"}]
 
 
 def run(secs: float, seed: int, verbose: bool = True):
@@ -47,7 +48,7 @@ def run(secs: float, seed: int, verbose: bool = True):
                 os.environ.pop(k, None)
             os.environ.update(KNOB_SETS[rnd.randint(len(KNOB_SETS))])
             w = 16 * int(rnd.randint(64, 520))
-            h = int(rnd.choice([1, 2, 3, 17, 63, 64, 65, 66, 127, 130, 257, 300]))
+            h = int(rnd.choice([1, 2, 3, 16, 17, 32, 48, 63, 64, 65, 66, 127, 128, 130, 192, 256, 257, 300]))
             ch = int(rnd.choice([3, 3, 4]))
             if rnd.randint(3) == 0:                              # widths that are not multiples of 16
                 w += int(rnd.randint(1, 16))
