@@ -399,10 +399,13 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         return false;
     };
     if (REG) {                                       // nch >= 3 chunks, all of them full
-        static_assert(!REG || D == 3, "the exact count of the second chunk's first step needs the two steps before it to have stored");
+        // the exact count of a chunk's first step needs the D - 1 steps before it to have stored: true from chunk 1 on when the first
+        // chunk's last D - 1 steps store (CHK - 2 >= D - 1), else from chunk 2 on
         chunk(std::integral_constant<int, 3>{}, 0);
+        int ch = 1;
+        if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); ch = 2; }
 #pragma unroll 1
-        for (int ch = 1; ch < nch - 1; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
+        for (; ch < nch - 1; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
         chunk(std::integral_constant<int, 4>{}, nch - 1);
         return;
     }
@@ -813,6 +816,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                     if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);     // regular-band form, other depths
+                    else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     else
 #endif
                     k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
