@@ -297,13 +297,16 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // per unrolled step -- first chunk: steps 0, 1 store nothing; last chunk: the last D - 1 steps issue nothing -- and the band runs
 // without a single data-dependent branch.  That is what keeps this kernel inside 256 registers at ring depth 3: the generic form's
 // early exits cost 70 more (allocated as AGPR spills in the tail, but they halve the residency of the whole kernel).
-template <int D, int LB = 1, int REG = 0>
+// UNAL: rows of frames whose pitch or base is not a multiple of 16 start at the aligned address before the strip pair and land
+// dword-shifted (1), plus the byte re-alignment of both strips (2) -- exactly k_sobel_dma's scheme on a 2 KiB row.
+template <int D, int LB = 1, int REG = 0, int UNAL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                   int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
     using namespace stream_core;
     constexpr int SW = 2 * STRIP_PX;
-    constexpr int SLOT = SW + 16;
+    constexpr int PRE = UNAL ? 16 : 0;
+    constexpr int SLOT = UNAL ? 16 + SW + 32 : SW + 16;
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;
     static_assert(5 * (D - 1) <= 60, "vmcnt is 6 bits");
     __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
@@ -329,11 +332,24 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     st0.clear();
     st1.clear();
 
-    auto issue_row = [&](int i, int slot) {
+    const bool has_right = xw + SW < w;
+    auto strip_row = [&](int i) {                                // first byte of the strip pair in band row i (wave-uniform)
         const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
-        const uint8_t *rowb = uniform_ptr(src + (ptrdiff_t)yy * w);
+        return uniform_ptr(src + (ptrdiff_t)yy * w + xw);
+    };
+    auto issue_row = [&](int i, int slot) {                      // always exactly 3 vector-memory instructions
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
-        glds_row2k_halo(d, d + SW, rowb, voff, hoff, slot);          // always exactly 3 vector-memory instructions
+        if (UNAL) {                                              // see k_sobel_dma: a', the tail blocks, the landing offset
+            const uint8_t *A = strip_row(i);
+            const uint32_t a = (uint32_t)(uintptr_t)A & 15u;
+            const uint32_t ap = (a == 0u && xw > 0) ? 16u : a;
+            const uint32_t t0 = (ap == 0u && !has_right) ? (uint32_t)SW - 16u : (uint32_t)SW;
+            const uint32_t t1 = (ap == 16u && has_right) ? (uint32_t)SW + 16u : t0;
+            const uint32_t dm = uniform_u32(d + PRE + (a & 3u) - ap);
+            glds_row2k_tail(dm, dm + SW, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
+        } else {
+            glds_row2k_halo(d, d + SW, strip_row(i) - xw, voff, hoff, slot);
+        }
     };
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) issue_row(i, i);
@@ -354,17 +370,28 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
             wait_vm<0>(j % D);
         }
         const uint8_t *slotp = &ring[wave][j % D][0];
-        const uint4 q0 = *reinterpret_cast<const uint4 *>(slotp + 16 * lane);
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(slotp + STRIP_PX + 16 * lane);
-        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + SW);
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(slotp + PRE + 16 * lane);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(slotp + PRE + STRIP_PX + 16 * lane);
+        uint2 hh;                                                    // the dword in front of the lane grid, the dword behind it
+        if (UNAL) hh = make_uint2(*reinterpret_cast<const uint32_t *>(slotp + PRE - 4), *reinterpret_cast<const uint32_t *>(slotp + PRE + SW));
+        else hh = *reinterpret_cast<const uint2 *>(slotp + SW);
+        const uint32_t sh = UNAL == 2 ? (uint32_t)(uintptr_t)strip_row(i) & 3u : 0u;     // the pair starts at byte sh of the lane grid
         const int y = y0 + i - 2;
         const bool zero_row = (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
-        auto strip = [&](auto sub_c, StateF2 &st, const uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
+        auto strip = [&](auto sub_c, StateF2 &st, uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
             constexpr int SUB = decltype(sub_c)::value;
             uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
             uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
             if (lane == 0) ql = left_of_lane0;
             if (lane == 63) qr = right_of_lane63;
+            if (UNAL == 2) {
+                ql = __builtin_amdgcn_alignbyte(q.x, ql, sh);
+                q.x = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+                q.y = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+                q.z = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+                q.w = __builtin_amdgcn_alignbyte(qr, q.w, sh);
+                qr >>= 8u * sh;
+            }
             const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
             f32x2 G[10];
 #pragma unroll
@@ -796,18 +823,21 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
             // frames with unaligned rows: GH_SOBEL_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_sobel_dma, UNAL), 1 = pieces
             // from the strip's own unaligned address, 0 = register-staged strips + column tail (further down)
-            // Two strips per wave (k_sobel_dma2, regular-band form): aligned frames whose rows split into whole bands of 64 or 16 rows
+            // Two strips per wave (k_sobel_dma2, regular-band form): frames whose rows split into whole bands of 64 or 16 rows
             // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/r2_call_ai.sh,
             // r2_call_aj.sh): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
             // 0.0521 / 0.0262 vs 0.0309 / 0.0166 vs 0.0185, 8192^2 0.0270 vs 0.0288, 7680 x 4352 0.0230 vs 0.0246; narrow or small
             // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
             // 64-row bands when they still give every CU a workgroup, else 16.  GH_SOBEL_NS = 1: never, 2: whenever the geometry allows.
             const int ns_knob = GH_TUNE_INT("GH_SOBEL_NS", 0);
-            if (aligned && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
+            const int unal2 = aligned ? 0 : (GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
+            if (unal2 >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
                 const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
                 const int R2 = r_env > 0 ? r_env : ((rows % 64 == 0 && (long long)gx2 * (rows / 64) >= GH_NUM_CU) ? 64 : 16);
                 const bool regular = R2 >= 16 && rows % R2 == 0 && (R2 + 2) % 6 == 0;           // every band: R2 + 2 input rows = whole chunks of 6
-                if (regular && (ns_knob == 2 || (pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU))) {
+                // (frames with unaligned rows only on request: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
+                //  one strip per wave -- the gain belongs to row pitches that keep the row streams in step; 16368 wide: 0.1079 vs 0.1086)
+                if (regular && (ns_knob == 2 || (unal2 == 0 && pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU))) {
                     stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
                     p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2);
                     const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
@@ -820,7 +850,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                     else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     else
 #endif
-                    k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     GH_LAUNCH_CHECK();
                     return GH_OK;
                 }

@@ -384,6 +384,12 @@ __device__ __forceinline__ void glds_row1k_tail(uint32_t lds_slot, uint32_t lds_
     uint64_t keepx;
     asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_TAIL GH_GLDS_OPS);
 }
+__device__ __forceinline__ void glds_row2k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    uint64_t keepx;
+    asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_PIECE(" offset:1024", " nt") GH_GLDS_TAIL GH_GLDS_OPS);
+}
 __device__ __forceinline__ void glds_row3k_tail(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
 {
     uint32_t keep;

@@ -725,6 +725,31 @@ def test_sobel_two_strips_per_wave(pkg, oracle, torch_mod, w, h, band_rows, monk
     assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1]).cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("w,h", [(2048, 16), (2049, 16), (2050, 32), (2051, 16), (2052, 48), (2060, 64), (4100, 32), (4099, 128), (6147, 16), (16370, 32), (16380, 64)])
+def test_sobel_two_strips_per_wave_unaligned_rows(pkg, oracle, torch_mod, w, h, monkeypatch):
+    """k_sobel_dma2 on frames whose rows are not 16-byte aligned (aligned-down pieces, dword-shifted landing, byte re-alignment of
+    both strips and of the pixels they exchange), every input base offset 0..15, whole frames and a band with real halo rows;
+    guard bytes around the output."""
+    monkeypatch.setenv("GH_SOBEL_NS", "2")
+    t = torch_mod
+    plane = oracle.frame_rand(w, h + 2, 1, seed=w * 3 + h).reshape(h + 2, w)
+    want = oracle.sobel(plane[1:h + 1])
+    want_band = oracle.sobel(plane)[1:h + 1]
+    n = (h + 2) * w
+    for so in range(16):
+        raw_in = t.zeros(n + 48, dtype=t.uint8, device="cuda")
+        raw_out = t.full((h * w + 48,), 0x5A, dtype=t.uint8, device="cuda")
+        src = raw_in[so:so + n].view(h + 2, w)
+        do = (so * 7) % 16
+        dst = raw_out[do:do + h * w].view(h, w)
+        src.copy_(dev(t, plane))
+        pkg.hostapi.sobel(src[1:h + 1], out=dst)
+        assert np.array_equal(dst.cpu().numpy(), want), ("frame", so)
+        assert (raw_out[:do] == 0x5A).all() and (raw_out[do + h * w:] == 0x5A).all(), ("guard", so)
+        pkg.hostapi.sobel_rows(src, dst, h, False, False)
+        assert np.array_equal(dst.cpu().numpy(), want_band), ("band", so)
+
+
 @pytest.mark.parametrize("w", [1024, 1025, 1027, 1030, 1036, 1039, 1040, 2051, 2064, 3073])
 def test_every_base_alignment_through_the_ring_kernels(pkg, oracle, torch_mod, w):
     """The aligned-down LDS-DMA rows (UNAL variants) take a different branch per (address mod 16) of a strip's first byte: piece

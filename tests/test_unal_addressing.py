@@ -14,5 +14,5 @@ def test_no_block_outside_the_frame_and_every_needed_byte_fetched():
     spec = importlib.util.spec_from_file_location("unal_address_model", os.path.join(ROOT, "tools", "unal_address_model.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    n = m.sweep(list(range(1024, 1045)) + [2047, 2049, 2051, 3073, 4099], offsets=range(16))
+    n = m.sweep(list(range(1024, 1045)) + [2047, 2048, 2049, 2051, 2064, 3073, 4099, 4100], offsets=range(16))
     assert n > 10000
