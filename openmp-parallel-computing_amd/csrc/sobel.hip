@@ -833,11 +833,20 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const int unal2 = aligned ? 0 : (GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
             if (unal2 >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
                 const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
-                const int R2 = r_env > 0 ? r_env : ((rows % 64 == 0 && (long long)gx2 * (rows / 64) >= GH_NUM_CU) ? 64 : 16);
-                const bool regular = R2 >= 16 && rows % R2 == 0 && (R2 + 2) % 6 == 0;           // every band: R2 + 2 input rows = whole chunks of 6
+                const int R2 = r_env > 0 ? r_env : ((long long)gx2 * (rows / 64) >= GH_NUM_CU ? 64 : 16);
+                const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
+                const bool wanted = ns_knob == 2 || (unal2 == 0 && pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU);
+                // rows that do not split into whole bands: the whole bands here, the ragged rest (fewer than R2 rows, real halo row above) in a
+                // second launch that falls through to the one-strip kernel
+                if (band_ok && wanted && rows % R2 != 0 && rows > R2) {
+                    const int main_rows = rows - rows % R2;
+                    if (int rc = gh_sobel_u8_rows_dev(src, dst, width, main_rows, top_is_border, 0, stream)) return rc;
+                    return gh_sobel_u8_rows_dev(src + (size_t)main_rows * width, dst + (size_t)main_rows * width, width, rows - main_rows, 0, bottom_is_border, stream);
+                }
+                const bool regular = band_ok && rows % R2 == 0;
                 // (frames with unaligned rows only on request: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
                 //  one strip per wave -- the gain belongs to row pitches that keep the row streams in step; 16368 wide: 0.1079 vs 0.1086)
-                if (regular && (ns_knob == 2 || (unal2 == 0 && pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU))) {
+                if (regular && wanted) {
                     stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
                     p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2);
                     const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);

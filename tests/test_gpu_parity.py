@@ -725,6 +725,21 @@ def test_sobel_two_strips_per_wave(pkg, oracle, torch_mod, w, h, band_rows, monk
     assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1]).cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("w,h,band_rows", [(4096, 70, ""), (2048, 17, ""), (8192, 200, "64"), (8192, 65, "64"), (6160, 47, "16"), (2050, 35, "")])
+def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
+    """Rows that do not split into whole bands: k_sobel_dma2 takes the whole bands, the ragged rest goes through a second launch (the
+    one-strip kernel on a band with a real halo row above)."""
+    monkeypatch.setenv("GH_SOBEL_NS", "2")
+    if band_rows:
+        monkeypatch.setenv("GH_SOBEL_R", band_rows)
+    plane = oracle.frame_rand(w, h + 2, 1, seed=w + 5 * h).reshape(h + 2, w)
+    d = dev(torch_mod, plane)
+    assert np.array_equal(pkg.hostapi.sobel(d).cpu().numpy(), oracle.sobel(plane))
+    out = torch_mod.empty((h, w), dtype=torch_mod.uint8, device="cuda")
+    pkg.hostapi.sobel_rows(d, out, h, False, False)
+    assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane)[1:h + 1])
+
+
 @pytest.mark.parametrize("w,h", [(2048, 16), (2049, 16), (2050, 32), (2051, 16), (2052, 48), (2060, 64), (4100, 32), (4099, 128), (6147, 16), (16370, 32), (16380, 64)])
 def test_sobel_two_strips_per_wave_unaligned_rows(pkg, oracle, torch_mod, w, h, monkeypatch):
     """k_sobel_dma2 on frames whose rows are not 16-byte aligned (aligned-down pieces, dword-shifted landing, byte re-alignment of
