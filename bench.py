@@ -150,7 +150,7 @@ def measured_traffic(kernel_name: str, px: int):
     pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself.  A summary whose
     two passes averaged very different numbers of launches (an outlier filter gone wrong) is refused."""
     sym = {"gray_sobel_fused_rgb8": ("k_fused_dma", "k_fused_stream"), "gray_rgb8_to_plane": ("k_gray_rgb_to_plane_w",),
-           "sobel3x3_u8": ("k_sobel_dma", "k_sobel_stream")}
+           "sobel3x3_u8": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream")}
     try:
         latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
         f = os.path.join(ROOT, "profiles", latest, "pmc_hbm_traffic.json")

@@ -25,7 +25,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 src, dst = args[0], args[1]
 set_latest = "--no-latest" not in sys.argv
 os.makedirs(dst, exist_ok=True)
-ALGO = {"k_fused_dma": 4, "k_fused_stream": 4, "k_gray_rgb_to_plane_w": 4, "k_sobel_dma": 2, "k_sobel_stream": 2, "k_copy_stream": 2,
+ALGO = {"k_fused_dma": 4, "k_fused_stream": 4, "k_gray_rgb_to_plane_w": 4, "k_sobel_dma2": 2, "k_sobel_dma": 2, "k_sobel_stream": 2, "k_copy_stream": 2,
         "k_gray_inplace_rgb_w": 6}
 NPIX = 16384 * 16384
 NSIMD = 1024                      # 256 CUs x 4 SIMDs

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel statistics and counters of the contract bench command.
 #   usage: tools/profile_round.sh <out dir under gpurun_out/>
 # The default bench command times the fused pipeline (its `value`) and, in a second timed region, the split pipeline,
-# so ONE command covers k_fused_dma, k_gray_rgb_to_plane_w and k_sobel_dma.  Kernel trace / stats and the PMC passes are
+# so ONE command covers k_fused_dma, k_gray_rgb_to_plane_w and k_sobel_dma2.  Kernel trace / stats and the PMC passes are
 # separate processes (never combined); FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), the SQ / GRBM counters in
 # a third.  The program follows `--` directly (no env / bash -c hop).
 set -e -o pipefail
