@@ -13,8 +13,10 @@ One "step" = one pass of the hot path over one frame that is already resident in
     --pipeline fused (default): ONE kernel, RGB -> luma -> Sobel edge plane, 3 R + 1 W bytes per pixel
                                 (the luma plane never leaves the chip);
     --pipeline split          : gray_rgb8_to_plane (3 R + 1 W B/px) then sobel3x3_u8 (1 R + 1 W B/px).
-N = 1: `value` comes from K steps of the chosen pipeline; a second timed region of K steps of the OTHER pipeline follows,
-so that every headline kernel (fused, RGB -> gray, plane Sobel) has a HIP-event figure measured inside a timed region.
+N = 1: `value` comes from K steps of the chosen pipeline; a second timed region of K steps of the OTHER pipeline follows, and a
+third of K steps of the plane Sobel on its own (three rotating luma planes resident in HBM), so that every headline kernel has a
+HIP-event figure measured inside a timed region: `kernels.sobel3x3_u8` is the kernel on its own, `kernels.sobel3x3_u8_after_gray`
+the same kernel inside the gray -> Sobel pipeline, where it starts the moment its input plane has been written (~5 % slower).
 N > 1: the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with each neighbour over
 RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three step forms are timed, each with the
 contract's bracket (barrier + synchronize on both sides, MAX over ranks):
@@ -52,6 +54,7 @@ ALGO_BYTES_PER_PX = {          # each image byte counted
     "gray_sobel_fused_rgb8": 4,  # 3 R + 1 W
     "gray_rgb8_to_plane": 4,     # 3 R + 1 W
     "sobel3x3_u8": 2,            # 1 R + 1 W
+    "sobel3x3_u8_after_gray": 2,  # the same kernel timed inside the gray -> Sobel pipeline (its input plane has just been written)
     "gray_inplace_rgb8": 6,      # 3 R + 3 W (the reference ABI's in-place form)
 }
 M64 = (1 << 64) - 1
@@ -150,7 +153,7 @@ def measured_traffic(kernel_name: str, px: int):
     pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself.  A summary whose
     two passes averaged very different numbers of launches (an outlier filter gone wrong) is refused."""
     sym = {"gray_sobel_fused_rgb8": ("k_fused_dma", "k_fused_stream"), "gray_rgb8_to_plane": ("k_gray_rgb_to_plane_w",),
-           "sobel3x3_u8": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream")}
+           "sobel3x3_u8": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream"), "sobel3x3_u8_after_gray": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream")}
     try:
         latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
         f = os.path.join(ROOT, "profiles", latest, "pmc_hbm_traffic.json")
@@ -397,13 +400,19 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn, k_steps, events=None):
+    def timed(step_fn, k_steps, events=None, region_events=None):
         """The contract's bracket: barrier + synchronize, EXACTLY k_steps steps, barrier + synchronize; MAX over ranks.
-        Returns (seconds, host seconds spent enqueueing)."""
+        Returns (seconds, host seconds spent enqueueing).  `events`: per-step HIP events the step function records (needed to tell
+        two kernels of one step apart; every record costs ~2.5 us of GPU time between launches); `region_events`: ONE pair recorded
+        on the launch stream around the K steps -- the kernel's average launch duration without any instrumentation between launches."""
         fence()
         t0 = time.perf_counter()
+        if region_events:
+            region_events[0].record(stream)
         for k in range(k_steps):
             step_fn(k, events[k] if events else None)
+        if region_events:
+            region_events[1].record(stream)
         host = time.perf_counter() - t0
         fence()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
@@ -523,22 +532,30 @@ def main() -> int:
 
         first, second = (step_fused, step_split) if fused else (step_split, step_fused)
         n_first, n_second = (2, 3) if fused else (3, 2)
-        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(n_first)] for _ in range(args.steps)]
+        # One kernel per step (fused): a single event pair around the K steps -- nothing between the launches, the average launch
+        # duration includes the ~1.5 us between two dependent launches and nothing else.  Two kernels per step (split): per-step
+        # events, which cost the step ~5 us (round 2 until here timed the fused region that way too: 0.1813 ms by events, 0.1868 by
+        # the wall clock -- `value` paid for the instrumentation).
+        def region_pair():
+            return [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+        ev1 = None if fused else [[torch.cuda.Event(enable_timing=True) for _ in range(n_first)] for _ in range(args.steps)]
+        rv1 = region_pair()
         run_in(first)
-        elapsed, host_enqueue = timed(first, args.steps, ev1)
-        step_ms_events = sum(e[0].elapsed_time(e[-1]) for e in ev1) / args.steps
+        elapsed, host_enqueue = timed(first, args.steps, ev1, rv1)
+        step_ms_events = rv1[0].elapsed_time(rv1[1]) / args.steps
         timed_kernels, region_of = {}, {}
 
-        def note(events, is_fused, region):
+        def note(events, is_fused, region, pair=None):
             if is_fused:
-                timed_kernels["gray_sobel_fused_rgb8"] = sum(e[0].elapsed_time(e[-1]) for e in events) / len(events)
+                timed_kernels["gray_sobel_fused_rgb8"] = pair[0].elapsed_time(pair[1]) / args.steps
                 region_of["gray_sobel_fused_rgb8"] = region
             else:
                 timed_kernels["gray_rgb8_to_plane"] = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
-                timed_kernels["sobel3x3_u8"] = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
-                region_of["gray_rgb8_to_plane"] = region_of["sobel3x3_u8"] = region
+                timed_kernels["sobel3x3_u8_after_gray"] = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+                region_of["gray_rgb8_to_plane"] = region_of["sobel3x3_u8_after_gray"] = region
 
-        note(ev1, fused, "value")
+        note(ev1, fused, "value", rv1)
         # parity of what was just timed: the WHOLE frame against the compiled reference's SHA-256 (tests/golden/known_answers.json)
         if not args.no_check:
             if is_known_frame and KA:
@@ -564,10 +581,11 @@ def main() -> int:
         # kernel) also have in-region HIP-event figures
         other = None
         if not args.no_kernel_table:
-            ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(n_second)] for _ in range(args.steps)]
+            ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(n_second)] for _ in range(args.steps)] if fused else None
+            rv2 = region_pair()
             run_in(second)
-            el2, _ = timed(second, args.steps, ev2)
-            note(ev2, not fused, "second")
+            el2, _ = timed(second, args.steps, ev2, rv2)
+            note(ev2, not fused, "second", rv2)
             other = {"pipeline": "split" if fused else "fused", "ms_per_step": round(el2 / args.steps * 1e3, 4),
                      "Mpixels/s": round(W * H_total * args.steps / el2 / 1e6, 1)}
             if not args.no_check and is_known_frame and KA:
@@ -582,6 +600,36 @@ def main() -> int:
                     check += "; split pipeline: luma and edge planes == compiled reference"
                 else:
                     check += "; fused pipeline: edge plane == compiled reference"
+
+        # third timed region: the plane Sobel on its own (the reference's sobel_edge is a function of its own too, sobel.c:6-25) -- same
+        # bracket, same K, luma planes resident in HBM before the region starts, inputs and outputs rotating over three planes each
+        # (a single 268 MB plane re-read launch after launch could be served by the 256 MB Infinity Cache).  Inside the split pipeline
+        # above the same kernel starts the moment its input plane has been written and measures ~5 % slower: both figures are reported.
+        sobel_alone = None
+        if not args.no_kernel_table:
+            if not luma[1:rows + 1].any():                                   # (the split pipeline was the FIRST region or did not run)
+                chk(lib.gh_gray_rgb8_to_plane_dev(rgb_ptr, luma_ptr + W, rows * W, 3, mode, s_ptr), "gray")
+            lumas = [luma, luma.clone(), luma.clone()]
+            edges = [edge, torch.empty_like(edge), torch.empty_like(edge)]
+            lp, ep = [t.data_ptr() + W for t in lumas], [t.data_ptr() for t in edges]
+
+            def step_sobel(k, ev):
+                chk(lib.gh_sobel_u8_rows_dev(lp[k % 3], ep[k % 3], W, rows, 1, 1, s_ptr), "sobel")
+
+            rv3 = region_pair()
+            run_in(step_sobel)
+            el3, _ = timed(step_sobel, args.steps, None, rv3)
+            timed_kernels["sobel3x3_u8"] = rv3[0].elapsed_time(rv3[1]) / args.steps
+            region_of["sobel3x3_u8"] = "third"
+            sobel_alone = {"pipeline": "plane Sobel alone, inputs / outputs rotating over 3 planes", "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                           "Mpixels/s": round(W * H_total * args.steps / el3 / 1e6, 1)}
+            if not args.no_check and is_known_frame and KA:
+                for e_ in edges:
+                    if sha256_of(e_) != KA[ka_mode]["rand1_16384"]["edge"]:
+                        print("bench.py: parity check FAILED in the third timed region", file=sys.stderr)
+                        return 3
+                check += "; plane Sobel alone: all three edge planes == compiled reference"
+            del lumas, edges
 
         # outside the timed regions: the in-place reference-ABI kernel, and the copy ceiling of this GPU
         def time_kernel(fn, reps=30):
@@ -626,7 +674,7 @@ def main() -> int:
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "frac_of_copy_ceiling": round(a / copy_ceiling, 4) if copy_ceiling else None}
         out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
-                    "kernels": kern_table, "ms_per_step_events": round(step_ms_events, 4), "second_timed_region": other,
+                    "kernels": kern_table, "ms_per_step_events": round(step_ms_events, 4), "second_timed_region": other, "third_timed_region": sobel_alone,
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1)})
         parallelism = "single GPU"
@@ -693,20 +741,17 @@ def main() -> int:
             def fn(_k, ev):          # the step number runs on through run-in, warm-up and timed steps: the frame ring never skips
                 k = calls[name]
                 calls[name] = k + 1
-                if ev:
-                    ev[0].record(stream)
                 impl(k)
-                if ev:
-                    ev[1].record(stream)
             return fn
 
         def run_form(impl, k_steps, name):
-            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(k_steps)]
+            # one HIP-event pair around the K steps (per-step pairs cost every step ~5 us of GPU time: 12 % of a 40 us sharded step)
+            pair = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
             fn = with_events(impl, name)
             run_in(fn)
-            el, host = timed(fn, k_steps, ev)
+            el, host = timed(fn, k_steps, None, pair)
             return {"ms_per_step": round(el / k_steps * 1e3, 4), "Mpixels/s": round(W * H_total * k_steps / el / 1e6, 1),
-                    "ms_per_step_events_rank0": round(sum(e[0].elapsed_time(e[1]) for e in ev) / k_steps, 4),
+                    "ms_per_step_events_rank0": round(pair[0].elapsed_time(pair[1]) / k_steps, 4),
                     "host_enqueue_us_per_step": round(host * 1e6 / k_steps, 1), "steps": k_steps}, el
 
         forms = {}
