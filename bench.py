@@ -16,7 +16,7 @@ One "step" = one pass of the hot path over one frame that is already resident in
 N = 1: `value` comes from K steps of the chosen pipeline; a second timed region of K steps of the OTHER pipeline follows, and a
 third of K steps of the plane Sobel on its own (three rotating luma planes resident in HBM), so that every headline kernel has a
 HIP-event figure measured inside a timed region: `kernels.sobel3x3_u8` is the kernel on its own, `kernels.sobel3x3_u8_after_gray`
-the same kernel inside the gray -> Sobel pipeline, where it starts the moment its input plane has been written (~5 % slower).
+the same kernel inside the gray -> Sobel pipeline, between two per-step event records (which cost ~2.5 us each: ~4 % on this kernel).
 N > 1: the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with each neighbour over
 RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three step forms are timed, each with the
 contract's bracket (barrier + synchronize on both sides, MAX over ranks):
@@ -604,7 +604,7 @@ def main() -> int:
         # third timed region: the plane Sobel on its own (the reference's sobel_edge is a function of its own too, sobel.c:6-25) -- same
         # bracket, same K, luma planes resident in HBM before the region starts, inputs and outputs rotating over three planes each
         # (a single 268 MB plane re-read launch after launch could be served by the 256 MB Infinity Cache).  Inside the split pipeline
-        # above the same kernel starts the moment its input plane has been written and measures ~5 % slower: both figures are reported.
+        # above the same kernel is timed between two per-step event records, which cost it ~4 %: both figures are reported.
         sobel_alone = None
         if not args.no_kernel_table:
             if not luma[1:rows + 1].any():                                   # (the split pipeline was the FIRST region or did not run)
