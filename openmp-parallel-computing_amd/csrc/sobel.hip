@@ -286,7 +286,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
-// ---- two strips per wave (aligned frames, width >= 2048): a wave owns 2 KiB of every row -----------------------------------------
+// ---- two strips per wave (width >= 2048): a wave owns 2 KiB of every row ----------------------------------------------------------
 // The no-arithmetic skeletons run faster the more contiguous bytes ONE wave reads and writes per row (1 KiB:
 // 67-69 %, 2 KiB: 68-69 %, 4 KiB: 72 % of 8 TB/s).  The rolling Sobel state is 64 VGPRs per 1,024 columns, so two strips per wave
 // is what fits in 256 registers: the same row step run on two neighbouring 1 KiB strips out of one ring slot (two DMA pieces + the
@@ -411,12 +411,8 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         // the pixel right of strip 0 is strip 1's first (lane 0, byte 0 of q1.x), the pixel left of strip 1 strip 0's last (lane 63, byte 3 of q0.w)
         const uint32_t first_of_1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.x);
         const uint32_t last_of_0 = (uint32_t)__builtin_amdgcn_readlane((int)q0.w, 63);
-        // (scheduling barriers: without them the compiler interleaves the two strips and the row steps and needs 326 registers)
-        __builtin_amdgcn_sched_barrier(0);
         strip(std::integral_constant<int, 0>{}, st0, q0, hh.x, first_of_1);
-        __builtin_amdgcn_sched_barrier(0);
         strip(std::integral_constant<int, 1>{}, st1, q1, last_of_0, hh.y);
-        __builtin_amdgcn_sched_barrier(0);
         return false;
     };
     auto chunk = [&](auto kind_c, int ch) {
