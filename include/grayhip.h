@@ -89,7 +89,7 @@ GH_API int gh_gray_inplace_dev(uint8_t *data, size_t npix, int channels, int mod
 GH_API int gh_gray_inplace_passes_dev(uint8_t *data, size_t npix, int channels, int mode, int passes, gh_stream_t stream);
 
 /* 3x3 Sobel magnitude, u8 plane -> u8 plane, whole frame; border pixels are written as 0.
- * width<3 or height<3: dst is all zeros. */
+ * width<3 or height<3: dst is all zeros.  Any width and alignment (1024 columns and more: LDS-DMA ring kernels). */
 GH_API int gh_sobel_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, gh_stream_t stream);
 
 /* Row band of a frame (row sharding): computes `rows` output rows.  src/dst point at the band's
@@ -99,8 +99,8 @@ GH_API int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int
                                 int top_is_border, int bottom_is_border, gh_stream_t stream);
 
 /* Fused RGB -> luma -> Sobel; the luma plane never touches HBM.  Same band semantics as above
- * (halo rows are RGB rows).  3 R + 1 W bytes per pixel.  Any width and alignment; the fast kernels need
- * width % 16 == 0 and 16-byte aligned buffers, other frames run unaligned strips + a per-pixel column tail. */
+ * (halo rows are RGB rows).  3 R + 1 W bytes per pixel.  Any width and any alignment: frames of 1024 columns and more run the
+ * LDS-DMA ring kernel whatever their row pitch and base address, narrower ones register-staged strips / the per-pixel kernel. */
 GH_API int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels,
                                         int mode, int top_is_border, int bottom_is_border, gh_stream_t stream);
 
@@ -111,7 +111,8 @@ GH_API int gh_replicate_plane_dev(const uint8_t *plane, uint8_t *img, size_t npi
  * to pass k's output; not the identity for 13 grey levels in IEEE mode). */
 GH_API int gh_gray_of_plane_dev(const uint8_t *src, uint8_t *dst, size_t npix, int mode, gh_stream_t stream);
 
-/* generic 3x3 integer convolution on interleaved RGB8, zero border, out = clamp(trunc(sum/norm)) */
+/* generic 3x3 integer convolution on interleaved RGB8, zero border, out = clamp(trunc(sum/norm)); any width and alignment
+ * (rows of 1024 bytes and more: LDS-DMA ring kernel; 0 < |norm| <= 4096 and sum|k| * 255 < 2^24, else the per-pixel kernel) */
 GH_API int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height,
                                const int32_t kernel[9], int32_t norm, gh_stream_t stream);
 
