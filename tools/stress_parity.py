@@ -19,7 +19,7 @@ KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": 
              {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"}, {"GH_FUSED_DMA_ORDER": "4", "GH_SOBEL_ORDER": "4"},
              {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"},
              {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"},
-             {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"}]
+             {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_CONV_R": "16"}, {"GH_CONV_ORDER": "0"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"}]
 
 
 def run(secs: float, seed: int, verbose: bool = True):
@@ -60,6 +60,10 @@ def run(secs: float, seed: int, verbose: bool = True):
             want = O.sobel(luma)
             outs = [api.gray_sobel_fused(d, mode) for _ in range(3)]
             outs.append(api.sobel(torch.from_numpy(luma).cuda()))
+            conv = None
+            if ch == 3 and rnd.randint(3) == 0:                  # the 3x3 convolution's ring kernel shares the DMA machinery
+                kern, norm = [([1, 2, 1, 2, 4, 2, 1, 2, 1], 16), ([0, -1, 0, -1, 5, -1, 0, -1, 0], 1), ([1] * 9, 9), ([-1, -2, -1, 0, 0, 0, 1, 2, 1], 2)][rnd.randint(4)]
+                conv = (api.conv3x3(d, kern, norm), O.conv3x3(img, kern, norm))
             torch.cuda.synchronize()
             for o in outs:
                 n += 1
@@ -67,6 +71,12 @@ def run(secs: float, seed: int, verbose: bool = True):
                     bad += 1
                     if verbose:
                         print("MISMATCH", w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
+            if conv is not None:
+                n += 1
+                if not np.array_equal(conv[0].cpu().numpy(), conv[1]):
+                    bad += 1
+                    if verbose:
+                        print("MISMATCH conv", w, h, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
     finally:
         for k, v in saved.items():
             if v is None:
