@@ -20,8 +20,9 @@ the same kernel inside the gray -> Sobel pipeline, between two per-step event re
 N > 1: the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with each neighbour over
 RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three step forms are timed, each with the
 contract's bracket (barrier + synchronize on both sides, MAX over ranks):
-    pipelined     a stream of frames in a ring of three buffers; the halo of frame k+2 travels while frame k runs as one
-                  launch (`value`, as in round 1);
+    pipelined     a stream of frames in a ring of eight buffers; the halo rows of the next four frames travel in ONE exchange while
+                  the current four run, one launch per step (`value`; --halo-batch 0: one exchange per frame, two frames ahead,
+                  as in round 1);
     single_frame  ONE frame, strong-scaled (BASELINE configs[3] as written: the latency of one sharded frame): the one-row
                   exchange, then one launch over the shard (libgrayhip's default; its overlapped form -- exchange || interior
                   rows, then first and last row -- measured slower at every shard size, csrc/comm.hip);
@@ -79,6 +80,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second timed region and the per-kernel measurements")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="wall-clock budget of the CPU baseline matrix")
+    ap.add_argument("--halo-batch", type=int, default=1, choices=[0, 1],
+                    help="N > 1, pipelined form: 1 (default) the halo rows of four future frames per exchange (gh_sharded_prefetch_halos_dev), "
+                         "0 one exchange per frame, two frames ahead")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity checks")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed run-in before the W warm-up steps: after ~2 ms of load the GPU's power management dips the clocks and "
@@ -470,9 +474,11 @@ def main() -> int:
                 rccl_ranks = int(one.item())
 
     # Synthetic frames, resident in HBM before the timed region: SURVEY.md 8(c) rand(seed), this rank's rows of it.
-    # N = 1: one frame, rand(seed=1).  N > 1: a ring of three frames, rand(seed = 1, 2, 3) (a stream of frames, step k works
-    # on frame k % 3), so that the halo rows of a later frame can be exchanged while the current one is processed.
-    NBUF = 1 if single else 3
+    # N = 1: one frame, rand(seed=1).  N > 1: a ring of eight frames, rand(seed = 1 .. 8) (a stream of frames, step k works
+    # on frame k % 8), so that the halo rows of later frames can be exchanged while the current one is processed -- four frames
+    # per exchange in the batched form -- and so that the ring (8 x 100 MB per rank at N = 8) cannot live in the 256 MB Infinity Cache.
+    NBUF = 1 if single else 8
+    BATCH = 4
     row_bytes = W * 3
     aligned8 = (y0 * row_bytes) % 8 == 0 and (rows * row_bytes) % 8 == 0
     runners, rgbs = [], []
@@ -696,6 +702,8 @@ def main() -> int:
                     native_step = pstep
                     sstep = native.bind_fused_step(halo_bufs[0], edge_native, rows, mode)
                     native_single = lambda k: sstep()
+                    # batched form: the halos of BATCH future frames in one group, a step = one launch (checked below like the other)
+                    bstep = native.bind_fused_step_batched(halo_bufs, edge_native, rows, mode, BATCH) if args.halo_batch else None
                 else:
                     pstep = native.bind_sobel_step_pipelined(halo_bufs, edge_native, rows, ahead=AHEAD)
                     grays = [backend.bind_gray_to_plane(rgbs[i], halo_bufs[i][1:rows + 1]) for i in range(NBUF)]
@@ -722,13 +730,27 @@ def main() -> int:
                 native_single(0)
                 torch.cuda.synchronize()
                 same = same and bool(torch.equal(edge_native, runners[0].edge))
+                same_b = False
+                if same and fused and bstep is not None:
+                    same_b = True
+                    for k in range(2 * NBUF + BATCH):
+                        bstep(k)
+                        torch.cuda.synchronize()
+                        same_b = same_b and bool(torch.equal(edge_native, runners[k % NBUF].edge))
             except Exception as exc:
-                same, exchange_note = False, f"native step failed on rank {rank}: {exc}"
+                same, same_b, exchange_note = False, False, f"native step failed on rank {rank}: {exc}"
             if all_ranks_agree(same or rehearsal_loopback):
                 exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
                             f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed")
                 pipelined_impl, edge_of = native_step, (lambda k: edge_native)
                 single_impl, single_edge = native_single, edge_native
+                if fused and bstep is not None and all_ranks_agree(same_b or rehearsal_loopback):
+                    exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv groups on a side stream, issued from C++; "
+                                f"pipelined form: the halo rows of the next {BATCH} frames travel in ONE group while the current {BATCH} are "
+                                "processed, one launch per step")
+                    pipelined_impl = bstep        # (k runs on from 0 through run-in, warm-up and timed steps: a batch request every BATCH-th step)
+                elif fused and bstep is not None:
+                    exchange_note = exchange_note or "batched halo prefetch disagreed with torch.distributed on the first frames; one exchange per frame"
             else:
                 exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
                 native = None

@@ -191,11 +191,21 @@ GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t 
  * `stream`) are exchanged on the side stream.  The exchange latency, the cross-queue event latency and the two one-row
  * launches of the form above leave the critical path (request the halo two frames ahead: three buffers).  If cur's
  * halo was never requested (first calls, buffer changed) it is exchanged first; prefetch may be NULL or equal to cur.
- * At most 4 requests are remembered. */
+ * At most 4 single requests are remembered. */
 GH_API int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *prefetch_rgb_buf, uint8_t *edge,
                                                int width, int rows, int channels, int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge,
                                                int width, int rows, gh_stream_t stream);
+/* Batched prefetch for the pipelined steps: the halo rows of n (1..16) frame buffers -- (rows + 2) rows of row_bytes each, rows
+ * 1 / rows in place (enqueued on `stream`) -- are exchanged in ONE ncclGroup on the side stream, one event behind all of them.
+ * The pipelined steps that later run on these buffers (prefetch = NULL) find their halos requested: the first waits for the
+ * event, the others launch their kernel and nothing else.  One exchange per n frames instead of one per frame: fewer, larger
+ * collectives and fewer cross-queue hand-overs per step.  Up to 4 batches are remembered; all calls on one stream. */
+GH_API int gh_sharded_prefetch_halos_dev(gh_comm_t comm, uint8_t *const *bufs, int n, size_t row_bytes, int rows, gh_stream_t stream);
+/* Forgets every halo request that has not been consumed by a step.  The requests are remembered by buffer ADDRESS: a caller that
+ * drops prefetched buffers and later puts other frames at the same addresses calls this in between (a remembered request would
+ * otherwise be taken for the new frame's). */
+GH_API int gh_sharded_prefetch_reset(gh_comm_t comm);
 
 /* ---- the reference's historic entry points over `long` samples (old/parallel_*.c) --------------------------
  * Same argument meaning as the originals; the dimensions, compile-time macros of a utils.h that the reference does not

@@ -64,6 +64,8 @@ SIGNATURES = {
     "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
+    "gh_sharded_prefetch_halos_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int, _stream]),
+    "gh_sharded_prefetch_reset": (C.c_int, [C.c_void_p]),
     "gh_gray_sobel_streamed_rows_host": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                    C.POINTER(C.c_double)]),
     "gh_old_parallel_convolution": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int, C.c_int, C.c_long]),

@@ -90,11 +90,15 @@ struct Comm {
     hipEvent_t ready = nullptr, landed = nullptr;
     bool loopback = false;               // rehearsal on one GPU: both neighbours are this rank (ncclSend/ncclRecv to self)
     // pipelined steps: buffers whose halo rows the side stream has already been asked to fill, and the event that says
-    // they have landed.  A few entries, so that a halo can be requested two or three frames ahead.
-    static constexpr int kPrefetch = 4;
-    const void *pf_buf[kPrefetch] = {nullptr, nullptr, nullptr, nullptr};
+    // they have landed.  Requests come one buffer at a time (a halo two or three frames ahead) or as a BATCH -- the halos of
+    // several future frames in one ncclGroup, one event for all of them (gh_sharded_prefetch_halos_dev): kPrefetch events, each
+    // shared by the table entries of its batch; `pf_waited` says the caller's stream has already been told to wait for it.
+    static constexpr int kPrefetch = 4, kEntries = 32;
+    const void *pf_buf[kEntries] = {};
+    int pf_event_of[kEntries] = {};
     hipEvent_t pf_landed[kPrefetch] = {nullptr, nullptr, nullptr, nullptr};
-    int pf_next = 0;
+    bool pf_waited[kPrefetch] = {false, false, false, false};
+    int pf_next = 0, pf_next_entry = 0;
 };
 
 }  // namespace
@@ -252,41 +256,80 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
 // latency, the cross-queue event latency (~20 us on this runtime when the wait is reached before the signal) and the
 // two one-row launches of the form above leave the critical path once the halo is requested two frames ahead.  If
 // cur's halo has not been requested (first calls, or the caller changed buffers), it is exchanged first.
+static int pf_find(const Comm *c, const void *p)
+{
+    for (int i = 0; i < Comm::kEntries; ++i)
+        if (c->pf_buf[i] == p) return i;
+    return -1;
+}
+
+// Asks the side stream to fill the halo rows of n frame buffers in ONE ncclGroup (per buffer: my first row up, my last row down,
+// the neighbours' rows into rows 0 and rows + 1) and records one event behind it.  Reads the buffers' rows 1 / rows (written by
+// earlier work on s) and overwrites their halo rows (last read by earlier work on s): the side stream first waits for an event
+// recorded on s here.  Returns the table entry of the FIRST buffer (>= 0) or a negative status.
+static int prefetch_halos(Comm *c, uint8_t *const *bufs, int n, size_t row_bytes, int rows, hipStream_t s, int up, int down)
+{
+    const int ev = c->pf_next;
+    c->pf_next = (c->pf_next + 1) % Comm::kPrefetch;
+    for (int i = 0; i < Comm::kEntries; ++i)          // entries of the batch that owned this event before: forgotten
+        if (c->pf_buf[i] && c->pf_event_of[i] == ev) c->pf_buf[i] = nullptr;
+    c->pf_waited[ev] = false;
+    if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
+        return -gh_set_error(GH_ERR_HIP, "event hand-over to the exchange stream failed");
+    int r = g_rccl.GroupStart();
+    if (r != 0) return -gh_set_error(GH_ERR_HIP, "ncclGroupStart failed: %s", g_rccl.GetErrorString(r));
+    for (int k = 0; k < n; ++k) {
+        uint8_t *buf = bufs[k];
+        if (up >= 0) {
+            r |= g_rccl.Send(buf + row_bytes, row_bytes, kNcclUint8, up, c->nccl, c->side);
+            r |= g_rccl.Recv(buf, row_bytes, kNcclUint8, up, c->nccl, c->side);
+        }
+        if (down >= 0) {
+            r |= g_rccl.Send(buf + (size_t)rows * row_bytes, row_bytes, kNcclUint8, down, c->nccl, c->side);
+            r |= g_rccl.Recv(buf + (size_t)(rows + 1) * row_bytes, row_bytes, kNcclUint8, down, c->nccl, c->side);
+        }
+    }
+    const int e = g_rccl.GroupEnd();
+    if (r != 0 || e != 0) return -gh_set_error(GH_ERR_HIP, "halo exchange failed: %s", g_rccl.GetErrorString(r ? r : e));
+    if (hipEventRecord(c->pf_landed[ev], c->side) != hipSuccess) return -gh_set_error(GH_ERR_HIP, "hipEventRecord failed");
+    int first = -1;
+    for (int k = 0; k < n; ++k) {
+        int slot = -1;
+        for (int t = 0; t < Comm::kEntries && slot < 0; ++t) {        // next free entry, round robin
+            const int i = (c->pf_next_entry + t) % Comm::kEntries;
+            if (!c->pf_buf[i]) slot = i;
+        }
+        if (slot < 0) { slot = c->pf_next_entry; }                    // table full of stale requests: overwrite the oldest position
+        c->pf_next_entry = (slot + 1) % Comm::kEntries;
+        c->pf_buf[slot] = bufs[k];
+        c->pf_event_of[slot] = ev;
+        if (k == 0) first = slot;
+    }
+    return first;
+}
+
 template <typename Launch>
 static int sharded_step_pipelined(Comm *c, uint8_t *cur, uint8_t *prefetch, size_t row_bytes, int rows, hipStream_t s, Launch launch)
 {
     int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
     if (c->loopback) up = down = c->rank;
     if (up < 0 && down < 0) return launch(cur, 1, 1);
-    auto find = [&](const void *p) {
-        for (int i = 0; i < Comm::kPrefetch; ++i)
-            if (c->pf_buf[i] == p) return i;
-        return -1;
-    };
-    auto exchange = [&](uint8_t *buf) -> int {      // returns the table slot (>= 0) or a negative status
-        // reads buf's rows 1 / rows (written by earlier work on s), overwrites its halo rows (last read by earlier work on s)
-        const int slot = c->pf_next;
-        c->pf_next = (c->pf_next + 1) % Comm::kPrefetch;
-        c->pf_buf[slot] = nullptr;
-        if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
-            return -gh_set_error(GH_ERR_HIP, "event hand-over to the exchange stream failed");
-        if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
-                                          row_bytes, c->side))
-            return rc < 0 ? rc : -rc;
-        if (hipEventRecord(c->pf_landed[slot], c->side) != hipSuccess) return -gh_set_error(GH_ERR_HIP, "hipEventRecord failed");
-        c->pf_buf[slot] = buf;
-        return slot;
-    };
-    int slot = find(cur);
-    if (slot < 0) {
-        slot = exchange(cur);
-        if (slot < 0) return -slot;
+    int entry = pf_find(c, cur);
+    if (entry < 0) {
+        uint8_t *one[1] = {cur};
+        entry = prefetch_halos(c, one, 1, row_bytes, rows, s, up, down);
+        if (entry < 0) return -entry;
     }
-    GH_HIP_TRY(hipStreamWaitEvent(s, c->pf_landed[slot], 0));   // cur's halo rows have landed
-    c->pf_buf[slot] = nullptr;
-    if (prefetch && prefetch != cur && find(prefetch) < 0) {
+    const int ev = c->pf_event_of[entry];
+    if (!c->pf_waited[ev]) {                          // one wait per batch: the frames that share the event find it done
+        GH_HIP_TRY(hipStreamWaitEvent(s, c->pf_landed[ev], 0));   // cur's halo rows have landed
+        c->pf_waited[ev] = true;
+    }
+    c->pf_buf[entry] = nullptr;
+    if (prefetch && prefetch != cur && pf_find(c, prefetch) < 0) {
         // `ready` is recorded BEFORE cur's kernel is launched, so the exchange runs beside it
-        const int ps = exchange(prefetch);
+        uint8_t *one[1] = {prefetch};
+        const int ps = prefetch_halos(c, one, 1, row_bytes, rows, s, up, down);
         if (ps < 0) return -ps;
     }
     return launch(cur, up < 0, down < 0);
@@ -306,6 +349,32 @@ int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, ui
     return sharded_step_pipelined(c, cur_rgb_buf, prefetch_rgb_buf, rb, rows, (hipStream_t)stream, [&](uint8_t *buf, int tb, int bb) {
         return gh_gray_sobel_fused_rows_dev(buf + rb, edge, width, rows, channels, mode, tb, bb, stream);
     });
+}
+
+int gh_sharded_prefetch_reset(gh_comm_t comm)
+{
+    GH_REQUIRE(comm, "null communicator");
+    Comm *c = static_cast<Comm *>(comm);
+    for (int i = 0; i < Comm::kEntries; ++i) c->pf_buf[i] = nullptr;
+    return GH_OK;
+}
+
+int gh_sharded_prefetch_halos_dev(gh_comm_t comm, uint8_t *const *bufs, int n, size_t row_bytes, int rows, gh_stream_t stream)
+{
+    GH_REQUIRE(comm && bufs, "null pointer");
+    GH_REQUIRE(n >= 1 && n <= Comm::kEntries / 2, "between 1 and 16 buffers per batch");
+    GH_REQUIRE(rows >= 1 && row_bytes >= 1, "empty shard");
+    for (int k = 0; k < n; ++k) GH_REQUIRE(bufs[k], "null buffer");
+    Comm *c = static_cast<Comm *>(comm);
+    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback) up = down = c->rank;
+    if (up < 0 && down < 0) return GH_OK;             // a single rank: nothing to exchange
+    for (int k = 0; k < n; ++k) {                      // a buffer asked for again: its old request is forgotten
+        const int i = pf_find(c, bufs[k]);
+        if (i >= 0) c->pf_buf[i] = nullptr;
+    }
+    const int first = prefetch_halos(c, bufs, n, row_bytes, rows, (hipStream_t)stream, up, down);
+    return first < 0 ? -first : GH_OK;
 }
 
 int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge, int width, int rows,

@@ -149,10 +149,36 @@ class NativeHaloComm:
             assert tuple(b.shape) == (rows + 2, w, c) and b.is_contiguous()
         assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
         fn, chk, h, dst = self.lib.gh_sharded_fused_step_pipelined_dev, self.abi.check, self.handle, edge.data_ptr()
+        chk(self.lib.gh_sharded_prefetch_reset(h), "gh_sharded_prefetch_reset")      # requests are remembered by address: start clean
         ptrs, n = [b.data_ptr() for b in bufs], len(bufs)
         a = max(n - 1, 0) if ahead is None else ahead
         return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + a) % n], dst, w, rows, c, mode, torch.cuda.current_stream().cuda_stream),
                              "gh_sharded_fused_step_pipelined_dev")
+
+    def bind_fused_step_batched(self, bufs, edge, rows, mode, batch):
+        """Stream of frames cycling through len(bufs) >= 2 * batch buffers: every `batch` steps the halo rows of the NEXT `batch`
+        frames are exchanged in one group (gh_sharded_prefetch_halos_dev) while the current ones are processed; a step is one
+        kernel launch.  The returned closure takes the step number k and processes bufs[k % n]."""
+        import ctypes as C
+        import torch
+        w, c = bufs[0].shape[1], bufs[0].shape[2]
+        n = len(bufs)
+        assert batch >= 1 and n >= 2 * batch and n % batch == 0
+        for b in bufs:
+            assert tuple(b.shape) == (rows + 2, w, c) and b.is_contiguous()
+        assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
+        step, pre, chk, h, dst = self.lib.gh_sharded_fused_step_pipelined_dev, self.lib.gh_sharded_prefetch_halos_dev, self.abi.check, self.handle, edge.data_ptr()
+        chk(self.lib.gh_sharded_prefetch_reset(h), "gh_sharded_prefetch_reset")      # requests are remembered by address: start clean
+        ptrs = [b.data_ptr() for b in bufs]
+        groups = [(C.c_void_p * batch)(*[ptrs[(g * batch + i) % n] for i in range(batch)]) for g in range(n // batch)]
+        row_bytes = w * c
+
+        def fn(k):
+            s = torch.cuda.current_stream().cuda_stream
+            if k % batch == 0:                        # the frames of the batch AFTER this one
+                chk(pre(h, groups[((k // batch) + 1) % len(groups)], batch, row_bytes, rows, s), "gh_sharded_prefetch_halos_dev")
+            chk(step(h, ptrs[k % n], None, dst, w, rows, c, mode, s), "gh_sharded_fused_step_pipelined_dev")
+        return fn
 
     def bind_sobel_step_pipelined(self, lumas, edge, rows, ahead=None):
         import torch
@@ -161,6 +187,7 @@ class NativeHaloComm:
             assert tuple(b.shape) == (rows + 2, w) and b.is_contiguous()
         assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
         fn, chk, h, dst = self.lib.gh_sharded_sobel_step_pipelined_dev, self.abi.check, self.handle, edge.data_ptr()
+        chk(self.lib.gh_sharded_prefetch_reset(h), "gh_sharded_prefetch_reset")
         ptrs, n = [b.data_ptr() for b in lumas], len(lumas)
         a = max(n - 1, 0) if ahead is None else ahead
         return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + a) % n], dst, w, rows, torch.cuda.current_stream().cuda_stream),

@@ -619,6 +619,60 @@ def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):
         native_comm.set_loopback(False)
 
 
+@pytest.mark.parametrize("batch,nbuf", [(1, 2), (2, 4), (3, 6), (4, 8), (2, 8)])
+def test_native_batched_halo_prefetch_loopback(pkg, oracle, native_comm, torch_mod, batch, nbuf):
+    """Batched form of the pipelined step: every `batch` steps the halo rows of the next `batch` frames are exchanged in one group
+    (gh_sharded_prefetch_halos_dev) and each step is a single launch.  All frames differ and their halo rows start out as garbage,
+    so a halo that reached the wrong buffer, arrived late or was never exchanged changes the result; the frames are then
+    overwritten with new pixels between two passes over the ring (the next batch request must pick the new rows up)."""
+    t = torch_mod
+    w, h = 2064, 37
+
+    def expected(img):
+        padded = np.concatenate([img[:1], img, img[-1:]], axis=0)       # loopback: both neighbours are this shard
+        e = oracle.sobel(oracle.gray_to_plane(padded, 0))[1:-1]
+        e[:, 0] = 0
+        e[:, -1] = 0
+        return e
+
+    native_comm.set_loopback(True)
+    try:
+        frames = [oracle.frame_rand(w, h, 3, seed=100 + s) for s in range(nbuf)]
+        bufs = []
+        for img in frames:
+            b = t.full((h + 2, w, 3), 0x77, dtype=t.uint8, device="cuda")
+            b[1:h + 1] = dev(t, img)
+            bufs.append(b)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_step_batched(bufs, edge, h, 0, batch)
+        k = 0
+        for _ in range(2 * nbuf + 1):                                   # synchronised: every step checked
+            step(k)
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[k % nbuf])), k
+            k += 1
+        while k % nbuf:                                                 # finish the pass over the ring
+            step(k)
+            k += 1
+        t.cuda.synchronize()
+        # new pixels in every buffer (enqueued on the same stream, as the contract asks), halo rows poisoned again
+        frames = [oracle.frame_rand(w, h, 3, seed=500 + s) for s in range(nbuf)]
+        for b, img in zip(bufs, frames):
+            b[1:h + 1] = dev(t, img)
+            b[0] = 0x33
+            b[h + 1] = 0x44
+        results = []
+        for _ in range(2 * nbuf):                                       # unsynchronised: results copied out on the stream
+            step(k)
+            results.append((k, edge.clone()))
+            k += 1
+        t.cuda.synchronize()
+        for kk, e in results[batch:]:            # (the first `batch` frames of this pass had been requested before the overwrite:
+            assert np.array_equal(e.cpu().numpy(), expected(frames[kk % nbuf])), kk       # a caller refreshes frames BEFORE their batch request)
+    finally:
+        native_comm.set_loopback(False)
+
+
 @pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3),
                                    (1025, 5, 3), (1025, 67, 4), (1026, 130, 3), (3073, 65, 3), (2037, 90, 3), (16370, 24, 3),
                                    (2052, 40, 3), (1044, 9, 3), (16380, 24, 3), (5000, 33, 3), (1039, 66, 4), (1028, 35, 4), (1030, 7, 3)])

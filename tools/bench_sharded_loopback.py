@@ -19,15 +19,24 @@ for world in WORLDS:
     buf2, buf3 = buf.clone(), buf.clone()
     pstep = comm.bind_fused_step_pipelined([buf, buf2], edge, rows, 0)
     pstep3 = comm.bind_fused_step_pipelined([buf, buf2, buf3], edge, rows, 0)
+    ring8 = [buf, buf2, buf3] + [buf.clone() for _ in range(5)]
+    bstep4 = comm.bind_fused_step_batched(ring8, edge, rows, 0, 4)
+    bstep2 = comm.bind_fused_step_batched(ring8, edge, rows, 0, 2)
     cnt = [0]
+    def batched4():
+        bstep4(cnt[0]); cnt[0] += 1
+    def batched2():
+        bstep2(cnt[0]); cnt[0] += 1
     def piped():
         pstep(cnt[0]); cnt[0] += 1
     def piped3():
         pstep3(cnt[0]); cnt[0] += 1
     for name, fn in (("native sharded step (exchange || interior, then edge rows)", step), ("native pipelined step, halo 1 frame ahead", piped),
-                     ("native pipelined step, halo 2 frames ahead", piped3), ("single launch, no exchange", whole)):
+                     ("native pipelined step, halo 2 frames ahead", piped3), ("native batched step, halos of 4 frames per exchange (ring of 8)", batched4),
+                     ("native batched step, halos of 2 frames per exchange (ring of 8)", batched2), ("single launch, no exchange", whole)):
         if ONLY and ONLY not in name: continue
-        for _ in range(20): fn()
+        cnt[0] = 0
+        for _ in range(24): fn()
         torch.cuda.synchronize()
         n = NSTEP
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
