@@ -84,6 +84,22 @@ int main() {
     OK(gh_malloc(&edge, (size_t)rows * w));
     for (int k = 0; k < 7; ++k) OK(gh_sharded_fused_step_pipelined_dev(comm, (uint8_t *)bufs[k % 3], (uint8_t *)bufs[(k + 2) % 3], (uint8_t *)edge, w, rows, 3, 0, nullptr));
     OK(gh_sharded_fused_step_dev(comm, (uint8_t *)bufs[0], (uint8_t *)edge, w, rows, 3, 0, nullptr));
+    {   // batched halo prefetch: groups of 2 on a ring of 4 (three of them the buffers above), then a reset and single requests again
+        void *b4 = nullptr;
+        OK(gh_malloc(&b4, (size_t)(rows + 2) * w * 3));
+        OK(gh_memset_dev(b4, 44, (size_t)(rows + 2) * w * 3, nullptr));
+        uint8_t *ring[4] = {(uint8_t *)bufs[0], (uint8_t *)bufs[1], (uint8_t *)bufs[2], (uint8_t *)b4};
+        OK(gh_sharded_prefetch_reset(comm));
+        for (int k = 0; k < 13; ++k) {
+            if (k % 2 == 0) OK(gh_sharded_prefetch_halos_dev(comm, &ring[((k / 2 + 1) % 2) * 2], 2, (size_t)w * 3, rows, nullptr));
+            OK(gh_sharded_fused_step_pipelined_dev(comm, ring[k % 4], nullptr, (uint8_t *)edge, w, rows, 3, 0, nullptr));
+        }
+        OK(gh_sharded_prefetch_reset(comm));
+        for (int k = 0; k < 5; ++k) OK(gh_sharded_fused_step_pipelined_dev(comm, ring[k % 4], ring[(k + 2) % 4], (uint8_t *)edge, w, rows, 3, 0, nullptr));
+        if (gh_sharded_prefetch_halos_dev(comm, ring, 17, (size_t)w * 3, rows, nullptr) == 0) { printf("FAIL oversized batch accepted\n"); return 1; }
+        OK(gh_stream_sync(nullptr));
+        OK(gh_free(b4));
+    }
     OK(gh_stream_sync(nullptr));
     OK(gh_comm_destroy(comm));
     for (auto &p : bufs) OK(gh_free(p));
