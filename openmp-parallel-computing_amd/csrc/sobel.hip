@@ -131,7 +131,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // early and the strip's first pixel sits at byte s = A mod 4 of the slot's lane grid: every ds_read stays naturally aligned.
 // UNAL = 1: s is 0 for every row (pitch and base multiples of 4): nothing else changes.  UNAL = 2: the lane's 16 pixels and
 // its two neighbours are re-aligned in registers, six v_alignbyte_b32 with the row's (wave-uniform) s.
-template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0>
+template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
 {
@@ -223,9 +223,10 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         if (KIND == 0 && i >= nrows) return true;                    // past the band: so is every later step -- the wave is done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
         if (PROBE == 3 || PROBE == 4) __builtin_amdgcn_s_barrier();  // probe: the workgroup's four strips advance row by row together (every wave must be live)
-        if (KIND != 0 || i + D - 1 < nrows) {
+        const bool issue = KIND == 0 ? i + D - 1 < nrows : (KIND == 4 ? j + D - 1 < CHK : true);     // KIND 3 / 4: regular bands, see k_sobel_dma2
+        if (issue) {
             issue_row(i + D - 1, (j + D - 1) % D);
-            if (KIND == 2) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
+            if (KIND == 2 || KIND == 4) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
         } else {
             wait_vm<0>(j % D);
         }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
         uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
         if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
-        if (KIND != 0 || i >= 2) {                                  // y = y0 + i - 2 < rows by construction of nrows
+        if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
             if (x == 0) out.x &= 0xffffff00u;
             if (x + 15 == w - 1) out.w &= 0x00ffffffu;
@@ -272,6 +273,15 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             if (row_step(kind_c, ch, j)) return true;
         return false;
     };
+    if (REG) {                                       // regular bands: see k_sobel_dma2
+        chunk(std::integral_constant<int, 3>{}, 0);
+        int chr = 1;
+        if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); chr = 2; }
+#pragma unroll 1
+        for (; chr < nch - 1; ++chr) chunk(std::integral_constant<int, 2>{}, chr);
+        chunk(std::integral_constant<int, 4>{}, nch - 1);
+        return;
+    }
     // chunks 0 .. n_full-1 hold only rows that exist and still issue a row: (ch + 1) * CHK - 1 + D - 1 < nrows
     const int n_full = (nrows - D + 1) / CHK;
     if (chunk(std::integral_constant<int, 0>{}, 0)) return;
@@ -800,6 +810,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             // measured on MI355X (16384-wide planes, tools/ab_fused.py --op sobel): 64-row bands win from 8192 rows up
             // (66-67 % of 8 TB/s vs 59-61 % for 32 / 16), 32 at 4096 rows, 16 below
             R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+            // ... except that the ring kernel has a branch-free "regular band" form for 16-row bands (below), which beats the 32-row
+            // choice wherever it applies: 12288 x 8192 0.0380 vs 0.0460 ms, 16384 x 4096 0.0301 vs 0.0309 (tools/r2_call_ay.sh)
+            if (R == 32 && use_dma && rows % 16 == 0 && GH_TUNE_INT("GH_SOBEL_REG", 1)) R = 16;
         }
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
@@ -831,7 +844,9 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
                 const int R2 = r_env > 0 ? r_env : ((long long)gx2 * (rows / 64) >= GH_NUM_CU ? 64 : 16);
                 const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
-                const bool wanted = ns_knob == 2 || (unal2 == 0 && pairs >= 4 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU);
+                // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
+                //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips)
+                const bool wanted = ns_knob == 2 || (unal2 == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU);
                 // rows that do not split into whole bands: the whole bands here, the ragged rest (fewer than R2 rows, real halo row above) in a
                 // second launch that falls through to the one-strip kernel
                 if (band_ok && wanted && rows % R2 != 0 && rows > R2) {
@@ -863,7 +878,18 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 }
             }
             const int unal = aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? 0 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
-            if (unal && sp == 0) {
+            // Regular-band (branch-free) form of the one-strip kernel, 128-134 VGPRs: every band has R + 2 input rows in whole chunks of 6.
+            // With 16-row bands -- the mid-size and small frames, where a wave's row step is latency-bound and the generic form's scalar
+            // branches count -- it is 7-20 % faster (7680 x 4352 0.0198 vs 0.0249 ms, 4096^2 0.0115 vs 0.0129, 16384 x 1024 0.0117 vs 0.0134,
+            // 3840 x 2160 0.0108 vs 0.0119, 1920 x 1088 0.0100 vs 0.0107); with 64-row bands on large frames it only lets a third workgroup
+            // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.  GH_SOBEL_REG=0: never.
+            const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows % R == 0 && plan.n[1] == 0 && plan.order < 1000;
+            if (reg1) {
+                if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                else k_sobel_dma<3, 0, 2, 1, 2, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            }
+            else if (unal && sp == 0) {
                 if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
                 else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
             } else if (unal) {
