@@ -278,7 +278,9 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 // UNAL != 0 (frames whose rows or base are not 16-byte aligned): every row's pieces start at the 16-byte aligned address at or
 // before the strip (far enough before it to carry the left halo pixel) and land dword-shifted in LDS; UNAL = 2 re-aligns the
 // lane's bytes with v_alignbyte_b32 -- see k_sobel_dma in sobel.hip for the scheme and the counters behind it.
-template <int MODE, int D, int SP, int CH = 3, int UNAL = 0>
+// REG = 1 ("regular bands", see k_sobel_dma2 in sobel.hip): every band has R + 2 input rows and that is a multiple of the unroll, so
+// which steps issue a row and which store is known per unrolled step and a band runs without a data-dependent branch.
+template <int MODE, int D, int SP, int CH = 3, int UNAL = 0, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK)
 void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
                  int zero_bot)
@@ -375,9 +377,11 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         const int i = ch * CHK + j;
         if (KIND == 0 && i >= nrows) return true;                    // past the band: so is every later step -- the wave is done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slot about to be refilled has been read
-        if (KIND != 0 || i + D - 1 < nrows) {
+        // KIND 3 / 4: first / last chunk of a regular band (j is a constant in the unrolled chunk)
+        const bool issue = KIND == 0 ? i + D - 1 < nrows : (KIND == 4 ? j + D - 1 < CHK : true);
+        if (issue) {
             issue_row(i + D - 1, (j + D - 1) % D);
-            if (KIND == 2) wait_vm<(NLD + 1) * (D - 1)>(j % D); else wait_vm<NLD * (D - 1)>(j % D);
+            if (KIND == 2 || KIND == 4) wait_vm<(NLD + 1) * (D - 1)>(j % D); else wait_vm<NLD * (D - 1)>(j % D);
         } else {
             wait_vm<0>(j % D);
         }
@@ -410,7 +414,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         uint4 out;
         if ((SP % 100) >= 10) out = make_uint4(wv[0] ^ wv[4] ^ wv[8] ^ hw, wv[1] ^ wv[5] ^ wv[9], wv[2] ^ wv[6] ^ wv[10], wv[3] ^ wv[7] ^ wv[4 * CH - 1]);   // probe: no compute
         else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
-        if (KIND != 0 || i >= 2) {                                  // y = y0 + i - 2 < rows by construction of nrows
+        if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
             if (x == 0) out.x &= 0xffffff00u;
             if (x + 15 == w - 1) out.w &= 0x00ffffffu;
@@ -428,6 +432,15 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
             if (row_step(kind_c, ch, j)) return true;
         return false;
     };
+    if (REG) {                                       // nch >= 3 chunks, all of them full (host: rows % R == 0, (R + 2) % CHK == 0, R + 2 >= 3 CHK)
+        chunk(std::integral_constant<int, 3>{}, 0);
+        int chr = 1;
+        if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); chr = 2; }
+#pragma unroll 1
+        for (; chr < nch - 1; ++chr) chunk(std::integral_constant<int, 2>{}, chr);
+        chunk(std::integral_constant<int, 4>{}, nch - 1);
+        return;
+    }
     // chunks 0 .. n_full-1 hold only rows that exist and still issue a row: (ch + 1) * CHK - 1 + D - 1 < nrows
     const int n_full = (nrows - D + 1) / CHK;
     if (chunk(std::integral_constant<int, 0>{}, 0)) return;
@@ -472,16 +485,16 @@ __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__res
 struct DmaLaunch {
     const uint8_t *rgb; uint8_t *edge; int width, rows, groups_x; BandPlan plan; int zt, zb, channels, mode; unsigned grid; size_t pad; hipStream_t s;
 };
-template <int D, int SP, int UNAL = 0>
+template <int D, int SP, int UNAL = 0, int REG = 0>
 void launch_fused_dma(const DmaLaunch &L)
 {
     const unsigned b = stream_core::BLOCK;
     if (L.channels == 4) {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
     } else {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP, 3, UNAL><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        else k_fused_dma<GH_MODE_IEEE, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
     }
 }
 
@@ -576,7 +589,12 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             // the strip's own unaligned address, 0 = register-staged strips + column tail
             const int unal = aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 2) < 2 || dma == 4 ? 0
                              : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
-            if (sp == 2 && unal) {
+            // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
+            // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/r2_call_ba.sh); aligned frames only
+            const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows % 16 == 0 && plan.n[1] == 0 && plan.order < 1000;
+            if (reg) {
+                launch_fused_dma<3, 2, 0, 1>(L);
+            } else if (sp == 2 && unal) {
                 if (dma == 2) { if (unal == 1) launch_fused_dma<2, 2, 1>(L); else launch_fused_dma<2, 2, 2>(L); }
                 else { if (unal == 1) launch_fused_dma<3, 2, 1>(L); else launch_fused_dma<3, 2, 2>(L); }
             } else if (sp == 2) {               // production: nontemporal output stores
