@@ -164,7 +164,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
 // a multiple of 16 start at the aligned address before the strip and land dword-shifted (UNAL, see k_sobel_dma).  The last strip of
 // a row is shifted left to end at the row's last byte, so every strip is full.  Rows outside the frame and bytes outside a row are
 // zeros (the reference pre-pads its array).
-template <int D, int UNAL>
+// REG = 1: regular bands (every band R + 2 input rows in whole chunks of 6: the branch-free form of k_sobel_dma2 / k_sobel_dma).
+template <int D, int UNAL, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int wb, int h,
                                                                    int groups_x, stream_core::BandPlan plan, TapsF t)
 {
@@ -233,9 +234,10 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
         const int i = ch * CHK + j;
         if (KIND == 0 && i >= nrows) return true;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (KIND != 0 || i + D - 1 < nrows) {
+        const bool issue = KIND == 0 ? i + D - 1 < nrows : (KIND == 4 ? j + D - 1 < CHK : true);     // KIND 3 / 4: first / last chunk of a regular band
+        if (issue) {
             issue_row(i + D - 1, (j + D - 1) % D);
-            if (KIND == 2) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
+            if (KIND == 2 || KIND == 4) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
         } else {
             wait_vm<0>(j % D);
         }
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
             r[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(qf.x, k & 3, r[k >> 2]);
             r[2 + (k >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(qf.y, k & 3, r[2 + (k >> 2)]);
         }
-        if (KIND != 0 || i >= 2)                                     // y = y0 + i - 2 < h by construction of nrows
+        if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2))              // y = y0 + i - 2 < h by construction of nrows
             store_strip_p<2>(dst + (size_t)(y0 + i - 2) * wb + xw, lane, make_uint4(r[0], r[1], r[2], r[3]));
         return false;
     };
@@ -302,6 +304,15 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
             if (row_step(kind_c, ch, j)) return true;
         return false;
     };
+    if (REG) {
+        chunk(std::integral_constant<int, 3>{}, 0);
+        int chr = 1;
+        if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); chr = 2; }
+#pragma unroll 1
+        for (; chr < nch - 1; ++chr) chunk(std::integral_constant<int, 2>{}, chr);
+        chunk(std::integral_constant<int, 4>{}, nch - 1);
+        return;
+    }
     const int n_full = (nrows - D + 1) / CHK;
     if (chunk(std::integral_constant<int, 0>{}, 0)) return;
     int ch = 1;
@@ -346,11 +357,12 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
     if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_TUNE_INT("GH_CONV_DMA", 1)) {
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);
+        // Band height: 16 rows.  (This kernel had inherited the Sobel kernels' 64 / 32 / 16 rule untested.  Measured, tools/r2_call_bb.sh, bc:
+        // 16384^2 0.2954 ms with 16-row bands against 0.3137 with 64, 16370 x 16384 0.3332-0.3391 vs 0.3559, 12288 x 4096 0.0606 vs 0.0796,
+        // 7680 x 4352 0.0426 vs 0.0490; only 16384 x 4096 (0.0770 vs 0.0746) and 32768 x 8192 (32-row bands 0.2894, 16: 0.2974, 64: 0.3119)
+        // have a slightly better height.  At 97 registers five workgroups fit a CU, so short bands do not starve it of waves.)
         int R = GH_TUNE_INT("GH_CONV_R", 0);
-        if (R <= 0) {
-            const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
-            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
-        }
+        if (R <= 0) R = 16;
         stream_core::BandPlan plan = stream_core::make_band_plan(height, R, -1, 0, -1, 0);
         // pairs-per-XCD dispatch order (8): 0.290 ms against 0.293 (band-per-XCD) / 0.294 (plain) on 16384^2, ahead on 16368 / 16370 too
         plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x);
@@ -358,7 +370,12 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const int unal = aligned ? 0 : ((wb % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
-        if (unal == 0) k_conv3x3_dma<3, 0><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        // regular-band form: bands whose R + 2 input rows are whole chunks of 6 and into which the rows split (16- and 64-row bands)
+        const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height % R == 0 && plan.order < 1000;
+        if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        else if (reg) k_conv3x3_dma<3, 2, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        else if (unal == 0) k_conv3x3_dma<3, 0><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else if (unal == 1) k_conv3x3_dma<3, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else k_conv3x3_dma<3, 2><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         GH_LAUNCH_CHECK();
