@@ -565,7 +565,13 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
                 const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-                rd = nb64 >= GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+                // tall bands re-read fewer halo rows, but between one and two workgroups per CU they only pay when the workgroups spread
+                // evenly over the CUs: 16384 x 4096 (256 workgroups of 64-row bands, one per CU) 0.0495 vs 0.0555 ms with 16-row bands, but
+                // 12288 x 8192 (384 = 1.5 per CU) 0.0887 vs 0.0813 with 32-row and 0.0771 with 16-row bands, 10240^2 (480) 0.0887 vs 0.0840 with
+                // 32 (tools/r2_call_bd.sh): "balance" = workgroups / (CUs x rounds needed)
+                auto balance = [](long long nb) { const long long rounds = (nb + GH_NUM_CU - 1) / GH_NUM_CU; return (double)nb / (double)(rounds * GH_NUM_CU); };
+                rd = (nb64 >= 2 * GH_NUM_CU || (nb64 >= GH_NUM_CU && balance(nb64) >= 0.97)) ? 64
+                     : ((nb32 >= 2 * GH_NUM_CU && balance(nb32) >= 0.9) ? 32 : 16);
             }
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;
