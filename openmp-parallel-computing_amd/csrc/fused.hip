@@ -569,9 +569,17 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
                 // evenly over the CUs: 16384 x 4096 (256 workgroups of 64-row bands, one per CU) 0.0495 vs 0.0555 ms with 16-row bands, but
                 // 12288 x 8192 (384 = 1.5 per CU) 0.0887 vs 0.0813 with 32-row and 0.0771 with 16-row bands, 10240^2 (480) 0.0887 vs 0.0840 with
                 // 32 (tools/r2_call_bd.sh): "balance" = workgroups / (CUs x rounds needed)
-                auto balance = [](long long nb) { const long long rounds = (nb + GH_NUM_CU - 1) / GH_NUM_CU; return (double)nb / (double)(rounds * GH_NUM_CU); };
+                auto balance = [](long long nb) { return stream_core::wg_balance(nb, GH_NUM_CU); };
                 rd = (nb64 >= 2 * GH_NUM_CU || (nb64 >= GH_NUM_CU && balance(nb64) >= 0.97)) ? 64
                      : ((nb32 >= 2 * GH_NUM_CU && balance(nb32) >= 0.9) ? 32 : 16);
+                // band starts that alias onto a few channel phases (stream_core::prefer_short_bands): 10240 x 16384 0.1377 ms with 64-row
+                // bands, 0.1298 with 32; 12288 x 8192 0.0813 with 32, 0.0771 with 16
+                if (GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1)) {
+                    const long long pitch = (long long)width * channels;
+                    if (rd == 64 && stream_core::prefer_short_bands(pitch, 64, 32) && nb32 >= GH_NUM_CU) rd = 32;
+                    if (rd == 64 && stream_core::prefer_short_bands(pitch, 64, 16)) rd = 16;
+                    if (rd == 32 && stream_core::prefer_short_bands(pitch, 32, 16)) rd = 16;
+                }
             }
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;

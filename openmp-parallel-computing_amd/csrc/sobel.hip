@@ -810,6 +810,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             // measured on MI355X (16384-wide planes, tools/ab_fused.py --op sobel): 64-row bands win from 8192 rows up
             // (66-67 % of 8 TB/s vs 59-61 % for 32 / 16), 32 at 4096 rows, 16 below
             R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+            // tall bands whose starts alias onto a few channel phases lose to 16-row bands (stream_core::prefer_short_bands)
+            if (R == 64 && use_dma && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R = 16;
             // ... except that the ring kernel has a branch-free "regular band" form for 16-row bands (below), which beats the 32-row
             // choice wherever it applies: 12288 x 8192 0.0380 vs 0.0460 ms, 16384 x 4096 0.0301 vs 0.0309 (tools/r2_call_ay.sh)
             if (R == 32 && use_dma && rows % 16 == 0 && GH_TUNE_INT("GH_SOBEL_REG", 1)) R = 16;
@@ -842,7 +844,12 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             const int unal2 = aligned ? 0 : (GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
             if (unal2 >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
                 const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
-                const int R2 = r_env > 0 ? r_env : ((long long)gx2 * (rows / 64) >= GH_NUM_CU ? 64 : 16);
+                // 64-row bands from one workgroup per CU up -- below two per CU only when they spread evenly over the CUs (16384 x 12288: 384
+                // workgroups, 0.0863 ms against 0.0749 with 16-row bands)
+                const long long nb64_2 = (long long)gx2 * (rows / 64);
+                const bool even64 = nb64_2 >= 2 * GH_NUM_CU || (nb64_2 >= GH_NUM_CU && stream_core::wg_balance(nb64_2, GH_NUM_CU) >= 0.97);
+                int R2 = r_env > 0 ? r_env : (even64 ? 64 : 16);
+                if (r_env <= 0 && R2 == 64 && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R2 = 16;
                 const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
                 // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
                 //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips)

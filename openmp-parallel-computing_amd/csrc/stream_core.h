@@ -482,6 +482,36 @@ __device__ __forceinline__ void band_of_block(const BandPlan &plan, unsigned blk
 // The rolling Sobel window is symmetric under the reversal (gy changes sign, and is squared).
 __device__ __forceinline__ bool band_walks_up(const BandPlan &plan, int gy) { return (plan.order / 1000) % 10 == 2 && (gy & 1); }
 
+// ---- band height and channel aliasing (host side) ----------------------------------------------------------------------------------
+// The bands of a strip kernel start R * pitch bytes apart, and the ~256 row streams in flight advance together.  Measured on MI355X
+// (tools/r2_call_bg.sh: plane Sobel, R = 64 against R = 16): where the band starts take only a FEW distinct values modulo 1 MiB the
+// streams pile onto the same channels -- 12288-wide planes (64 rows = 768 KiB: 4 values) 0.0872 vs 0.0753 ms, 24576 wide (1.5 MiB: 2) 0.0910
+// vs 0.0755, 20480 wide (1.25 MiB: 4) 0.0785 vs 0.0633, 10240 wide (640 KiB: 8) 0.0864 vs 0.0681, 12288^2 0.0805 vs 0.0570 -- while ONE value
+// (16384- and 32768-wide planes: whole MiB, the address hash spreads the streams by their high bits) and MANY values (16368 / 16370 wide)
+// are both fine, and there the taller band wins on halo rows.  The same arithmetic explains why 16-row bands lose on 16384-wide planes
+// (256 KiB: 4 values).  band_start_phases() counts the values; prefer_short_bands() is the rule drawn from it.
+inline int band_start_phases(long long stride_bytes)
+{
+    const long long W = 1ll << 20;
+    long long a = stride_bytes % W, b = W;
+    if (a == 0) return 1;
+    while (b) { const long long t = a % b; a = b; b = t; }
+    return (int)(W / a);
+}
+// true: the tall band height aliases (2 .. 15 distinct band-start values) and the short one does better (one value, or more values)
+inline bool prefer_short_bands(long long pitch_bytes, int tall, int shrt)
+{
+    const int pt = band_start_phases((long long)tall * pitch_bytes), ps = band_start_phases((long long)shrt * pitch_bytes);
+    return pt > 1 && pt < 16 && (ps == 1 || ps > pt);
+}
+
+// workgroups / (CUs x rounds needed): 1.0 = every CU gets the same number of workgroups (matters below ~2 workgroups per CU)
+inline double wg_balance(long long nb, int num_cu)
+{
+    const long long rounds = (nb + num_cu - 1) / num_cu;
+    return rounds ? (double)nb / (double)(rounds * num_cu) : 0.0;
+}
+
 // host side: workgroups to launch for a plan (the band-per-XCD order pads the band count to a multiple of 8: surplus
 // workgroups find gy < 0 and exit)
 inline long long plan_grid(const BandPlan &plan, int groups_x)
