@@ -183,7 +183,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
     if (xw >= wb) return;
     if (xw + STRIP_PX > wb) xw = wb - STRIP_PX;
     if (gy_i < 0) return;
-    const int R = plan.R[0], y0 = gy_i * R;
+    const int R = plan.R[0];
+    int y0 = gy_i * R;
+    if (REG && y0 + R > h) y0 = h - R;          // regular bands: the last band is shifted up to end at the frame edge (see k_sobel_dma)
     const int nrows = min(R, h - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero (see the exactness note above)
@@ -371,7 +373,8 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         const int unal = aligned ? 0 : ((wb % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
         // regular-band form: bands whose R + 2 input rows are whole chunks of 6 and into which the rows split (16- and 64-row bands)
-        const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height % R == 0 && plan.order < 1000;
+        const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
+                         !stream_core::shifted_band_overflows(groups_x, height, R, 5, GH_NUM_CU);
         if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else if (reg) k_conv3x3_dma<3, 2, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);

@@ -313,6 +313,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
         if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
     }
+    if (REG && y0 + R > rows) y0 = rows - R;                     // regular bands: the last band is shifted up to end at the frame edge (see k_sobel_dma)
     const int nrows = min(R, rows - y0) + 2;                     // input rows of this band (clipped to the frame) incl. halo
     const int nch = (nrows + CHK - 1) / CHK;
     const bool up = band_walks_up(plan, gy_i);
@@ -432,7 +433,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
             if (row_step(kind_c, ch, j)) return true;
         return false;
     };
-    if (REG) {                                       // nch >= 3 chunks, all of them full (host: rows % R == 0, (R + 2) % CHK == 0, R + 2 >= 3 CHK)
+    if (REG) {                                       // nch >= 3 chunks, all of them full (host: rows >= R, (R + 2) % CHK == 0, R + 2 >= 3 CHK)
         chunk(std::integral_constant<int, 3>{}, 0);
         int chr = 1;
         if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); chr = 2; }
@@ -605,7 +606,8 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
                              : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
             // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
             // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/r2_call_ba.sh); aligned frames only
-            const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows % 16 == 0 && plan.n[1] == 0 && plan.order < 1000;
+            const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows >= 16 && plan.n[1] == 0 && plan.order < 1000 &&
+                             !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, GH_NUM_CU);
             if (reg) {
                 launch_fused_dma<3, 2, 0, 1>(L);
             } else if (sp == 2 && unal) {

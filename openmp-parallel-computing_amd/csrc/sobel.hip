@@ -161,6 +161,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         R = plan.R[1]; y0 = plan.y[1] + g1 * plan.R[1];
         if (g1 >= plan.n[1]) { R = plan.R[2]; y0 = plan.y[2] + (g1 - plan.n[1]) * plan.R[2]; }
     }
+    if (REG && y0 + R > rows) y0 = rows - R;    // regular bands: the last band is shifted UP to end at the frame edge (rows >= R): every band is
+                                                // full, the rows it shares with the band above are computed and stored twice with identical bytes
     const int nrows = min(R, rows - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
     const bool up = band_walks_up(plan, gy_i);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // halo dword per row, two stores), half as many waves, the per-row scalar work shared.  Between the two strips the neighbour
 // pixels come from the other strip's registers (v_readlane), not from LDS.
 // REG = 1 ("regular bands"): every band has exactly nrows = R + 2 input rows and nrows is a multiple of the unroll CHK (the host
-// checks rows % R == 0 and (R + 2) % CHK == 0: R = 64 or 16 with D = 3).  Then which steps issue a row and which store is known
+// checks rows >= R and (R + 2) % CHK == 0: R = 64 or 16 with D = 3; a last band that would be ragged is shifted up instead).  Then which steps issue a row and which store is known
 // per unrolled step -- first chunk: steps 0, 1 store nothing; last chunk: the last D - 1 steps issue nothing -- and the band runs
 // without a single data-dependent branch.  That is what keeps this kernel inside 256 registers at ring depth 3: the generic form's
 // early exits cost 70 more (allocated as AGPR spills in the tail, but they halve the residency of the whole kernel).
@@ -328,7 +330,9 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     if (xw >= w) return;
     if (xw + SW > w) xw = w - SW;                                // last pair of strips: shifted left to end at the frame edge
     if (gy_i < 0) return;
-    const int R = plan.R[0], y0 = gy_i * R;
+    const int R = plan.R[0];
+    int y0 = gy_i * R;
+    if (REG && y0 + R > rows) y0 = rows - R;    // regular bands: the last band is shifted up to end at the frame edge (see k_sobel_dma)
     const int nrows = min(R, rows - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
@@ -814,7 +818,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             if (R == 64 && use_dma && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R = 16;
             // ... except that the ring kernel has a branch-free "regular band" form for 16-row bands (below), which beats the 32-row
             // choice wherever it applies: 12288 x 8192 0.0380 vs 0.0460 ms, 16384 x 4096 0.0301 vs 0.0309 (tools/r2_call_ay.sh)
-            if (R == 32 && use_dma && rows % 16 == 0 && GH_TUNE_INT("GH_SOBEL_REG", 1)) R = 16;
+            if (R == 32 && use_dma && rows >= 16 && GH_TUNE_INT("GH_SOBEL_REG", 1) && !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, GH_NUM_CU)) R = 16;
         }
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
@@ -854,14 +858,17 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
                 //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips)
                 const bool wanted = ns_knob == 2 || (unal2 == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU);
-                // rows that do not split into whole bands: the whole bands here, the ragged rest (fewer than R2 rows, real halo row above) in a
-                // second launch that falls through to the one-strip kernel
-                if (band_ok && wanted && rows % R2 != 0 && rows > R2) {
+                // rows that do not split into whole bands: the kernel shifts the last band up -- unless the whole bands fill the 512 resident
+                // slots exactly; then the whole bands here and the ragged rest (fewer than R2 rows, real halo row above) in a second launch
+                // (the second launch costs ~10 us: only where the first one is long -- 16384 x 16390 0.1076 ms this way, 0.1146 on the one-strip kernel;
+                //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
+                const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, GH_NUM_CU);
+                if (overflow2 && (long long)width * rows >= (1ll << 28)) {
                     const int main_rows = rows - rows % R2;
                     if (int rc = gh_sobel_u8_rows_dev(src, dst, width, main_rows, top_is_border, 0, stream)) return rc;
                     return gh_sobel_u8_rows_dev(src + (size_t)main_rows * width, dst + (size_t)main_rows * width, width, rows - main_rows, 0, bottom_is_border, stream);
                 }
-                const bool regular = band_ok && rows % R2 == 0;
+                const bool regular = band_ok && rows >= R2 && !overflow2;                          // (a ragged last band is shifted up inside the kernel)
                 // (frames with unaligned rows only on request: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
                 //  one strip per wave -- the gain belongs to row pitches that keep the row streams in step; 16368 wide: 0.1079 vs 0.1086)
                 if (regular && wanted) {
@@ -890,7 +897,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             // branches count -- it is 7-20 % faster (7680 x 4352 0.0198 vs 0.0249 ms, 4096^2 0.0115 vs 0.0129, 16384 x 1024 0.0117 vs 0.0134,
             // 3840 x 2160 0.0108 vs 0.0119, 1920 x 1088 0.0100 vs 0.0107); with 64-row bands on large frames it only lets a third workgroup
             // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.  GH_SOBEL_REG=0: never.
-            const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows % R == 0 && plan.n[1] == 0 && plan.order < 1000;
+            const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows >= R && plan.n[1] == 0 && plan.order < 1000 &&
+                              !stream_core::shifted_band_overflows(groups_x, rows, R, 3, GH_NUM_CU);
             if (reg1) {
                 if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
                 else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
