@@ -562,6 +562,7 @@ def main() -> int:
                 region_of["gray_rgb8_to_plane"] = region_of["sobel3x3_u8_after_gray"] = region
 
         note(ev1, fused, "value", rv1)
+        kernel_forms = {"gray_sobel_fused_rgb8" if fused else "sobel3x3_u8_after_gray": lib.gh_last_kernel().decode()}   # which device-kernel form the launch rules picked
         # parity of what was just timed: the WHOLE frame against the compiled reference's SHA-256 (tests/golden/known_answers.json)
         if not args.no_check:
             if is_known_frame and KA:
@@ -592,6 +593,7 @@ def main() -> int:
             run_in(second)
             el2, _ = timed(second, args.steps, ev2, rv2)
             note(ev2, not fused, "second", rv2)
+            kernel_forms["sobel3x3_u8_after_gray" if fused else "gray_sobel_fused_rgb8"] = lib.gh_last_kernel().decode()
             other = {"pipeline": "split" if fused else "fused", "ms_per_step": round(el2 / args.steps * 1e3, 4),
                      "Mpixels/s": round(W * H_total * args.steps / el2 / 1e6, 1)}
             if not args.no_check and is_known_frame and KA:
@@ -626,6 +628,7 @@ def main() -> int:
             run_in(step_sobel)
             el3, _ = timed(step_sobel, args.steps, None, rv3)
             timed_kernels["sobel3x3_u8"] = rv3[0].elapsed_time(rv3[1]) / args.steps
+            kernel_forms["sobel3x3_u8"] = lib.gh_last_kernel().decode()
             region_of["sobel3x3_u8"] = "third"
             sobel_alone = {"pipeline": "plane Sobel alone, inputs / outputs rotating over 3 planes", "ms_per_step": round(el3 / args.steps * 1e3, 4),
                            "Mpixels/s": round(W * H_total * args.steps / el3 / 1e6, 1)}
@@ -670,6 +673,8 @@ def main() -> int:
                                 "frac_of_copy_ceiling": round(gbs / copy_ceiling, 4) if copy_ceiling else None,
                                 "Mpixels/s": round(px_rank / (ms * 1e-3) / 1e6, 1),
                                 "in_timed_region": region_of.get(name) is not None, "timed_region": region_of.get(name)}
+            if name in kernel_forms:
+                kern_table[name]["device_kernel"] = kernel_forms[name]
         first_kernels = {k: v for k, v in timed_kernels.items() if region_of[k] == "value"}
         dom = max(first_kernels, key=first_kernels.get)
         a = kern_table[dom]["GB/s"]

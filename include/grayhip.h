@@ -58,6 +58,9 @@ enum gh_status {
 GH_API int gh_init(int device);                 /* select device, warm the context; idempotent */
 GH_API int gh_device_count(void);
 GH_API const char *gh_last_error(void);
+/* Name of the device-kernel form the calling thread's last Sobel / fused / convolution launch took, e.g. "k_sobel_dma2 regular" or
+ * "k_fused_dma D=2" ("" before the first launch).  Diagnostic: lets a test assert that a shape runs the kernel it is meant to run. */
+GH_API const char *gh_last_kernel(void);
 GH_API const char *gh_version(void);
 GH_API int gh_default_mode(void);               /* GRAYHIP_MODE=ieee|fma, default ieee */
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "gh_init": (C.c_int, [C.c_int]),
     "gh_device_count": (C.c_int, []),
     "gh_last_error": (C.c_char_p, []),
+    "gh_last_kernel": (C.c_char_p, []),
     "gh_version": (C.c_char_p, []),
     "gh_default_mode": (C.c_int, []),
     "gh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),

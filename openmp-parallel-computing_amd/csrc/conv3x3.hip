@@ -375,6 +375,7 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         // regular-band form: bands whose R + 2 input rows are whole chunks of 6 and into which the rows split (16- and 64-row bands)
         const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
                          !stream_core::shifted_band_overflows(groups_x, height, R, 5, GH_NUM_CU);
+        gh_note_kernel(reg ? (unal ? "k_conv3x3_dma regular unaligned" : "k_conv3x3_dma regular") : (unal ? "k_conv3x3_dma unaligned" : "k_conv3x3_dma"));
         if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
         else if (reg) k_conv3x3_dma<3, 2, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
@@ -385,6 +386,7 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         return GH_OK;
     }
     const bool fast = exact && aligned;
+    gh_note_kernel(fast ? "k_conv3x3_stream" : "k_conv3x3_px");
     if (fast) {
         // band height: 64 rows whenever that still gives every CU two workgroups (the same rule as the Sobel kernels:
         // 64-row bands measured 5-10 % faster than 32 on MI355X), else 32, else 16

@@ -530,6 +530,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     const int dma_knob = GH_TUNE_INT("GH_FUSED_DMA", -1);      // ring depth D (0 = register-staged kernel, -1 = auto)
     const bool dma_ok = dma_knob != 0 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 1));
     if (!aligned && !dma_ok && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
+        gh_note_kernel("k_fused_px_cols");
         launch_px_cols(0);
         GH_LAUNCH_CHECK();
         return GH_OK;
@@ -608,6 +609,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/r2_call_ba.sh); aligned frames only
             const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows >= 16 && plan.n[1] == 0 && plan.order < 1000 &&
                              !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, GH_NUM_CU);
+            gh_note_kernel(reg ? "k_fused_dma regular R=16" : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
             if (reg) {
                 launch_fused_dma<3, 2, 0, 1>(L);
             } else if (sp == 2 && unal) {
@@ -643,6 +645,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             GH_LAUNCH_CHECK();
             return GH_OK;
         }
+        gh_note_kernel(ws < width ? "k_fused_stream + k_fused_px_cols" : "k_fused_stream");
         int pick = variant;
         if (pick == 0) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);

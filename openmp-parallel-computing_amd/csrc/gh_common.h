@@ -33,6 +33,10 @@ int gh_set_error(int status, const char *fmt, ...);
 
 int gh_ensure_init();   // lazy gh_init(GRAYHIP_DEVICE or 0)
 
+// which device kernel form the last launch of this thread took (gh_last_kernel(): tests and bench.py assert that the headline shapes run
+// the kernels DESIGN.md says they run, instead of silently falling to a slower form)
+void gh_note_kernel(const char *name);
+
 static inline bool gh_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // MI355X: 256 CUs in 8 XCDs

@@ -21,6 +21,7 @@
 namespace {
 
 thread_local char g_err[768] = "";
+thread_local const char *g_last_kernel = "";
 std::once_flag g_init_once;
 int g_init_rc = GH_OK;
 int g_device = -1;
@@ -88,6 +89,8 @@ struct EventTimer {
 
 }  // namespace
 
+void gh_note_kernel(const char *name) { g_last_kernel = name; }
+
 int gh_set_error(int status, const char *fmt, ...)
 {
     va_list ap;
@@ -142,6 +145,7 @@ int gh_device_count(void)
 }
 
 const char *gh_last_error(void) { return g_err; }
+const char *gh_last_kernel(void) { return g_last_kernel; }
 
 const char *gh_version(void) { return "grayhip 0.1 (gfx950)"; }
 

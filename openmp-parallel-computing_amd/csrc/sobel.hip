@@ -884,9 +884,12 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                     else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
                     else
 #endif
-                    if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                    else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                    else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    {
+                        gh_note_kernel(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
+                        if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                        else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                        else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    }
                     GH_LAUNCH_CHECK();
                     return GH_OK;
                 }
@@ -899,6 +902,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.  GH_SOBEL_REG=0: never.
             const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows >= R && plan.n[1] == 0 && plan.order < 1000 &&
                               !stream_core::shifted_band_overflows(groups_x, rows, R, 3, GH_NUM_CU);
+            gh_note_kernel(reg1 ? (unal ? "k_sobel_dma regular R=16 unaligned" : "k_sobel_dma regular R=16") : (unal ? "k_sobel_dma unaligned" : "k_sobel_dma"));
             if (reg1) {
                 if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
                 else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
@@ -971,6 +975,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
             GH_LAUNCH_CHECK();
             return GH_OK;
         }
+        gh_note_kernel(ws < width ? "k_sobel_stream + k_sobel_px_cols" : "k_sobel_stream");
 #define GH_SOBEL_LAUNCH(R_, C_)                                                                                      \
         do {                                                                                                         \
             if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);       \
@@ -993,10 +998,12 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
         const int tiles_y = (rows + TH - 1) / TH;
         const long long nt = (long long)tiles_x * tiles_y;
         GH_REQUIRE(nt < (1ll << 31), "frame too large for one launch");
+        gh_note_kernel("k_sobel_tiled");
         k_sobel_tiled<<<(unsigned)nt, BLOCK, 0, s>>>(src, dst, width, rows, tiles_x, zt, zb);
     } else {
         size_t blocks = ((size_t)width * rows + BLOCK - 1) / BLOCK;
         if (blocks > (1u << 20)) blocks = 1u << 20;
+        gh_note_kernel("k_sobel_px");
         k_sobel_px<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, rows, zt, zb);
     }
     GH_LAUNCH_CHECK();

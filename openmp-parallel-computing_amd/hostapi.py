@@ -221,6 +221,11 @@ def sobel(plane, out=None):
     return out
 
 
+def last_kernel() -> str:
+    """Which device-kernel form this thread's last Sobel / fused / convolution launch took (gh_last_kernel)."""
+    return abi.load().gh_last_kernel().decode()
+
+
 def sobel_rows(buf, out, rows: int, top_is_border: bool, bottom_is_border: bool):
     """Row band with halo storage: `buf` is (rows+2, w); rows 1..rows are the band, row 0 / rows+1 are
     the halo rows (ignored when the corresponding edge is the frame border).  `out` is (rows, w)."""

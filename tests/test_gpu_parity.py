@@ -779,6 +779,36 @@ def test_sobel_two_strips_per_wave(pkg, oracle, torch_mod, w, h, band_rows, monk
     assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1]).cpu().numpy(), want)
 
 
+def test_headline_shapes_run_the_kernels_they_are_meant_to_run(pkg, torch_mod):
+    """gh_last_kernel(): the launch rules must send the headline shapes to the kernel forms DESIGN.md names -- a regression that silently
+    fell back to a slower form (a changed threshold, a failed alignment test) would still be bit-exact and pass every parity test."""
+    t, api = torch_mod, pkg.hostapi
+    def sobel(w, h, off=0):
+        raw = t.zeros(h * w + 64, dtype=t.uint8, device="cuda")
+        api.sobel(raw[off:off + h * w].view(h, w))
+        return api.last_kernel()
+    def fused(w, h, c=3):
+        api.gray_sobel_fused(t.zeros((h, w, c), dtype=t.uint8, device="cuda"), 0)
+        return api.last_kernel()
+    assert sobel(16384, 16384) == "k_sobel_dma2 regular R=64"          # BASELINE configs[2]: two strips per wave, 64-row bands
+    assert sobel(16384, 2048) == "k_sobel_dma2 regular R=16"           # the shard of 8 GPUs
+    assert sobel(12288, 8192) == "k_sobel_dma regular R=16"            # off-step width: one strip, regular 16-row bands
+    assert sobel(1920, 1080) == "k_sobel_dma regular R=16"             # the reference's test image: ragged last band shifted up
+    assert sobel(16370, 16384) == "k_sobel_dma unaligned"              # unaligned rows, large: generic 64-row bands, aligned-down pieces
+    assert sobel(16384, 16384, off=5) == "k_sobel_dma unaligned"
+    assert sobel(2037, 1362) == "k_sobel_dma regular R=16 unaligned"
+    assert sobel(640, 480) in ("k_sobel_stream", "k_sobel_tiled")      # narrower than one strip
+    assert fused(16384, 16384) == "k_fused_dma D=2"                    # the bench's `value`
+    assert fused(16384, 2048) == "k_fused_dma regular R=16"
+    assert fused(16370, 16384) == "k_fused_dma D=2 unaligned"
+    assert fused(1920, 1080) == "k_fused_dma regular R=16"
+    assert fused(16384, 4096, 4) == "k_fused_dma D=3"
+    api.conv3x3(t.zeros((4096, 16384, 3), dtype=t.uint8, device="cuda"), [1, 2, 1, 2, 4, 2, 1, 2, 1], 16)
+    assert api.last_kernel() == "k_conv3x3_dma regular"
+    api.conv3x3(t.zeros((100, 5000, 3), dtype=t.uint8, device="cuda"), [1] * 9, 9)
+    assert api.last_kernel() == "k_conv3x3_dma regular unaligned"
+
+
 @pytest.mark.parametrize("w,h,band_rows", [(4096, 70, ""), (2048, 17, ""), (8192, 200, "64"), (8192, 65, "64"), (6160, 47, "16"), (2050, 35, "")])
 def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
     """Rows that do not split into whole bands: k_sobel_dma2 takes the whole bands, the ragged rest goes through a second launch (the
