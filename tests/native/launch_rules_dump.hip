@@ -1,0 +1,21 @@
+// Prints the host-side launch-rule helpers of stream_core.h for a list of cases (tests/test_launch_rules.py compares them with
+// a Python restatement and with the figures DESIGN.md quotes).  Host code only: built with hipcc, runs without a GPU.
+#include <cstdio>
+#include "stream_core.h"
+int main()
+{
+    const long long pitches[] = {16384, 32768, 16368, 16370, 12288, 10240, 20480, 24576, 8192, 15360, 7680, 4096, 49152, 36864, 30720, 49104};
+    for (long long p : pitches)
+        for (int r : {16, 32, 64})
+            printf("phases %lld %d %d\n", p, r, stream_core::band_start_phases((long long)r * p));
+    for (long long p : pitches) {
+        printf("prefer %lld 64 16 %d\n", p, (int)stream_core::prefer_short_bands(p, 64, 16));
+        printf("prefer %lld 64 32 %d\n", p, (int)stream_core::prefer_short_bands(p, 64, 32));
+        printf("prefer %lld 32 16 %d\n", p, (int)stream_core::prefer_short_bands(p, 32, 16));
+    }
+    const long long nbs[] = {1, 255, 256, 257, 384, 480, 500, 512, 513, 768, 1024, 1536};
+    for (long long nb : nbs) printf("balance %lld %.6f\n", nb, stream_core::wg_balance(nb, 256));
+    const int shapes[][3] = {{2, 8200, 64}, {2, 16390, 64}, {2, 8192, 64}, {1, 4100, 16}, {2, 4320, 16}, {1, 1080, 16}, {2, 3000, 16}, {3, 8200, 16}, {4, 4100, 16}, {4, 100000, 16}};
+    for (const auto &s : shapes) printf("overflow %d %d %d %d\n", s[0], s[1], s[2], (int)stream_core::shifted_band_overflows(s[0], s[1], s[2], 2, 256));
+    return 0;
+}
