@@ -39,8 +39,12 @@ def run(secs: float, seed: int, verbose: bool = True):
     allk = {k for d in KNOB_SETS for k in d} | {"GH_FUSED_UNALIGNED_MIN_PX", "GH_SOBEL_UNALIGNED_MIN_PX"}
     saved = {k: os.environ.get(k) for k in allk}
     t_end, n, bad = time.time() + secs, 0, 0
+    t_note = time.time() + 60
     try:
         while time.time() < t_end:
+            if verbose and time.time() >= t_note:             # a long run must not look hung
+                print(f"... {n} results checked, {bad} mismatches", flush=True)
+                t_note = time.time() + 60
             with torch.cuda.stream(side):                       # latency noise: 1 GiB of copy traffic in flight beside the kernels
                 for _ in range(4):
                     noise_b.copy_(noise_a, non_blocking=True)
