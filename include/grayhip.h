@@ -11,7 +11,7 @@
  *   gh_extract_plane_dev                  monolithic/src/main_with_sobel.c:57-59
  *   gh_replicate_plane_dev                monolithic/src/main_with_sobel.c:65-73
  *   gh_pipeline_*                         monolithic/src/main_with_sobel.c:49-76, monolithic/src/main.c:30-38
- *   gh_conv3x3_rgb8_dev                   old/parallel_convolution.c:8-24   (u8 frames, zero border)
+ *   gh_conv3x3_rgb8_dev / _rows_dev       old/parallel_convolution.c:8-24   (u8 frames, zero border; row bands with halo rows)
  *   gh_sum_rgb8_dev                       old/parallel_avg_pixel.c:5-42     (exact u64 channel sums)
  *   gh_mean_gray_minmax_dev               old/parallel_to_grayscale.c:7-38  (u8 frames)
  *   gh_old_parallel_*                     old/parallel_convolution.c:8, old/parallel_avg_pixel.c:5,
@@ -118,6 +118,11 @@ GH_API int gh_gray_of_plane_dev(const uint8_t *src, uint8_t *dst, size_t npix, i
  * (rows of 1024 bytes and more: LDS-DMA ring kernel; 0 < |norm| <= 4096 and sum|k| * 255 < 2^24, else the per-pixel kernel) */
 GH_API int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height,
                                const int32_t kernel[9], int32_t norm, gh_stream_t stream);
+/* Row band of a frame (row sharding of old/parallel_convolution.c:8-24): `rows` output rows, src/dst at the band's first row.  If
+ * !top_is_border the RGB row above the band (src - 3*width) must be readable and is a real row of the frame (a halo row); likewise
+ * below.  A band edge that IS the frame border sees the zero border there, as the whole-frame call does on all four sides. */
+GH_API int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, const int32_t kernel[9], int32_t norm,
+                                    int top_is_border, int bottom_is_border, gh_stream_t stream);
 
 /* exact per-channel sums of an RGB8 frame, ADDED into sums_dev[0..2] (device u64[3], zero it first) */
 GH_API int gh_sum_rgb8_dev(const uint8_t *rgb, size_t npix, uint64_t *sums_dev, gh_stream_t stream);
@@ -178,6 +183,12 @@ GH_API int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up
                                 const void *send_down, void *recv_down, size_t bytes, gh_stream_t stream);
 /* in-place sum of count u64 over all ranks (channel sums of old/parallel_avg_pixel.c on a sharded frame) */
 GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream);
+/* in place: minmax_dev[0] <- min over all ranks, minmax_dev[1] <- max over all ranks (ncclMin / ncclMax on one int32 each, one group):
+ * the `reduction(min:min_gray) reduction(max:max_gray)` of old/parallel_to_grayscale.c:12,36-37 on a sharded frame; every rank runs
+ * gh_mean_gray_minmax_dev on its rows first (a rank without rows keeps the initial 256 / -1, the neutral elements) */
+GH_API int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev, gh_stream_t stream);
+/* number of halo-row ncclGroups this communicator has issued so far (diagnostic: one per sharded step, one per batch of prefetched frames) */
+GH_API unsigned long long gh_comm_exchange_count(gh_comm_t comm);
 /* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default: the one-row
  * exchange is enqueued on `stream`, then ONE launch covers the shard.  GH_SHARD_STEP_SERIAL=0: the exchange runs on the
  * communicator's side stream while the interior rows run on `stream`; the first and last row follow once the halo has
@@ -188,6 +199,16 @@ GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream);
+/*   conv3x3: buf = RGB8 rows, the halo is one RGB row, dst = rows * width * 3 bytes (old/parallel_convolution.c:8-24 on a shard; the
+ *   frame's own top / bottom edge keeps the zero border) */
+GH_API int gh_sharded_conv3x3_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *dst, int width, int rows, const int32_t kernel[9],
+                                       int32_t norm, gh_stream_t stream);
+/* `passes` x (gray -> extract -> Sobel -> replicate) on a row shard, in place in rows 1..rows of img_buf ((rows + 2) rows of
+ * width * channels bytes): monolithic/src/main_with_sobel.c:49-76 on a sharded frame.  Pass k + 1 filters what pass k wrote, so there
+ * is ONE halo exchange per pass: an RGB row for pass 1 (fused kernel), a luma row -- lum(e, e, e) of the neighbour's edge row -- for
+ * every later pass.  gray_ws: (rows + 2) * width bytes, edge_ws: rows * width bytes of scratch (the last pass's edge plane on return). */
+GH_API int gh_sharded_pipeline_gray_sobel_dev(gh_comm_t comm, uint8_t *img_buf, int width, int rows, int channels, int passes, int mode,
+                                              uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream);
 /* Pipelined form for a STREAM of frames kept in a few such buffers: `cur` -- whose halo rows were requested by an
  * earlier call, where it was `prefetch` -- is processed by ONE launch over the whole shard while the halo rows of
  * `prefetch` (a frame that will be `cur` in a later call; its rows 1 / rows must already be in place, enqueued on

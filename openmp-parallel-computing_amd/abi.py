@@ -44,6 +44,7 @@ SIGNATURES = {
     "gh_replicate_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
     "gh_gray_of_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
     "gh_conv3x3_rgb8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int32, _stream]),
+    "gh_conv3x3_rgb8_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.c_int, _stream]),
     "gh_sum_rgb8_dev": (C.c_int, [_u8p, C.c_size_t, C.c_void_p, _stream]),
     "gh_mean_gray_minmax_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_void_p, _stream]),
     "gh_pipeline_gray_sobel_dev": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _stream]),
@@ -61,6 +62,10 @@ SIGNATURES = {
     "gh_comm_set_loopback": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_halo_exchange_dev": (C.c_int, [C.c_void_p, C.c_int, _u8p, _u8p, C.c_int, _u8p, _u8p, C.c_size_t, _stream]),
     "gh_comm_allreduce_sum_u64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _stream]),
+    "gh_comm_allreduce_minmax_i32_dev": (C.c_int, [C.c_void_p, C.c_void_p, _stream]),
+    "gh_comm_exchange_count": (C.c_ulonglong, [C.c_void_p]),
+    "gh_sharded_conv3x3_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int32, _stream]),
+    "gh_sharded_pipeline_gray_sobel_dev": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _stream]),
     "gh_sharded_fused_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),

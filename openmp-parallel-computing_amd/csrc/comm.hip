@@ -24,7 +24,7 @@ namespace {
 constexpr int kIdBytes = 128;
 struct NcclId { char internal[kIdBytes]; };
 using nccl_comm_t = void *;
-enum { kNcclUint8 = 1, kNcclUint64 = 5, kNcclSum = 0 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
+enum { kNcclUint8 = 1, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
 
 struct Rccl {
     void *so = nullptr;
@@ -91,14 +91,18 @@ struct Comm {
     bool loopback = false;               // rehearsal on one GPU: both neighbours are this rank (ncclSend/ncclRecv to self)
     // pipelined steps: buffers whose halo rows the side stream has already been asked to fill, and the event that says
     // they have landed.  Requests come one buffer at a time (a halo two or three frames ahead) or as a BATCH -- the halos of
-    // several future frames in one ncclGroup, one event for all of them (gh_sharded_prefetch_halos_dev): kPrefetch events, each
-    // shared by the table entries of its batch; `pf_waited` says the caller's stream has already been told to wait for it.
-    static constexpr int kPrefetch = 4, kEntries = 32;
+    // several future frames in one ncclGroup, one event for all of them (gh_sharded_prefetch_halos_dev): a pool of kPrefetch
+    // events, each shared by the table entries of its batch; `pf_waited` says the caller's stream has already been told to wait
+    // for it.  An event is taken for a new request only when none of its entries is still waiting to be consumed (round 2 took
+    // them round robin: with batches of 3-4 the single-request fallback recycled the event of the batch just requested for the
+    // NEXT frames and forgot it, so every step fell back to its own exchange -- correct pixels, one exchange per step).
+    static constexpr int kPrefetch = 8, kEntries = 32;
     const void *pf_buf[kEntries] = {};
     int pf_event_of[kEntries] = {};
-    hipEvent_t pf_landed[kPrefetch] = {nullptr, nullptr, nullptr, nullptr};
-    bool pf_waited[kPrefetch] = {false, false, false, false};
+    hipEvent_t pf_landed[kPrefetch] = {};
+    bool pf_waited[kPrefetch] = {};
     int pf_next = 0, pf_next_entry = 0;
+    unsigned long long exchanges = 0;    // ncclGroups issued for halo rows (gh_comm_exchange_count: tests and bench.py read it)
 };
 
 }  // namespace
@@ -199,14 +203,33 @@ int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void 
     }
     const int e = g_rccl.GroupEnd();
     if (r != 0 || e != 0) return gh_set_error(GH_ERR_HIP, "halo exchange failed: %s", g_rccl.GetErrorString(r ? r : e));
+    ++c->exchanges;
     return GH_OK;
 }
+
+unsigned long long gh_comm_exchange_count(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->exchanges : 0; }
 
 int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream)
 {
     GH_REQUIRE(comm && buf_dev, "null pointer");
     Comm *c = static_cast<Comm *>(comm);
     GH_NCCL_TRY(g_rccl.AllReduce(buf_dev, buf_dev, count, kNcclUint64, kNcclSum, c->nccl, (hipStream_t)stream));
+    return GH_OK;
+}
+
+// min and max of the mean-grey levels over all ranks (old/parallel_to_grayscale.c:12 `reduction(min:min_gray) reduction(max:max_gray)`,
+// :36-37): minmax_dev[0] <- min over ranks, minmax_dev[1] <- max over ranks, both in one group.  A rank without rows contributes the
+// reference's initial values 256 / -1, the neutral elements.
+int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev, gh_stream_t stream)
+{
+    GH_REQUIRE(comm && minmax_dev, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    hipStream_t s = (hipStream_t)stream;
+    GH_NCCL_TRY(g_rccl.GroupStart());
+    const int r0 = g_rccl.AllReduce(minmax_dev, minmax_dev, 1, kNcclInt32, kNcclMin, c->nccl, s);
+    const int r1 = g_rccl.AllReduce(minmax_dev + 1, minmax_dev + 1, 1, kNcclInt32, kNcclMax, c->nccl, s);
+    const int e = g_rccl.GroupEnd();
+    if (r0 != 0 || r1 != 0 || e != 0) return gh_set_error(GH_ERR_HIP, "min/max all-reduce failed: %s", g_rccl.GetErrorString(r0 ? r0 : (r1 ? r1 : e)));
     return GH_OK;
 }
 
@@ -269,10 +292,19 @@ static int pf_find(const Comm *c, const void *p)
 // recorded on s here.  Returns the table entry of the FIRST buffer (>= 0) or a negative status.
 static int prefetch_halos(Comm *c, uint8_t *const *bufs, int n, size_t row_bytes, int rows, hipStream_t s, int up, int down)
 {
-    const int ev = c->pf_next;
-    c->pf_next = (c->pf_next + 1) % Comm::kPrefetch;
-    for (int i = 0; i < Comm::kEntries; ++i)          // entries of the batch that owned this event before: forgotten
-        if (c->pf_buf[i] && c->pf_event_of[i] == ev) c->pf_buf[i] = nullptr;
+    int ev = -1;
+    for (int t = 0; t < Comm::kPrefetch && ev < 0; ++t) {            // next event none of whose requests is still unconsumed
+        const int cand = (c->pf_next + t) % Comm::kPrefetch;
+        bool live = false;
+        for (int i = 0; i < Comm::kEntries && !live; ++i) live = c->pf_buf[i] && c->pf_event_of[i] == cand;
+        if (!live) ev = cand;
+    }
+    if (ev < 0) {                                                     // every event still owns requests nobody came for: the oldest goes
+        ev = c->pf_next;
+        for (int i = 0; i < Comm::kEntries; ++i)
+            if (c->pf_buf[i] && c->pf_event_of[i] == ev) c->pf_buf[i] = nullptr;
+    }
+    c->pf_next = (ev + 1) % Comm::kPrefetch;
     c->pf_waited[ev] = false;
     if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
         return -gh_set_error(GH_ERR_HIP, "event hand-over to the exchange stream failed");
@@ -291,6 +323,7 @@ static int prefetch_halos(Comm *c, uint8_t *const *bufs, int n, size_t row_bytes
     }
     const int e = g_rccl.GroupEnd();
     if (r != 0 || e != 0) return -gh_set_error(GH_ERR_HIP, "halo exchange failed: %s", g_rccl.GetErrorString(r ? r : e));
+    ++c->exchanges;
     if (hipEventRecord(c->pf_landed[ev], c->side) != hipSuccess) return -gh_set_error(GH_ERR_HIP, "hipEventRecord failed");
     int first = -1;
     for (int k = 0; k < n; ++k) {
@@ -415,6 +448,59 @@ int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, 
     return sharded_step(c, luma_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
         return gh_sobel_u8_rows_dev(luma_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, tb, bb, stream);
     });
+}
+
+// 3x3 convolution of a row shard (old/parallel_convolution.c:8-24 on a sharded frame): buf holds
+// rows + 2 RGB rows, the halo is one RGB row per neighbour (the taps reach one row up and down); the frame's own top / bottom
+// edge keeps the zero border.
+int gh_sharded_conv3x3_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *dst, int width, int rows, const int32_t kernel[9], int32_t norm,
+                                gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(rgb_buf && dst && kernel, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width * 3;
+    return sharded_step(c, rgb_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
+        return gh_conv3x3_rgb8_rows_dev(rgb_buf + (size_t)(first + 1) * rb, dst + (size_t)first * rb, width, n, kernel, norm, tb, bb, stream);
+    });
+}
+
+// `passes` x (gray -> extract -> Sobel -> replicate) on a row shard (monolithic/src/main_with_sobel.c:49-76 on a sharded frame, SURVEY.md
+// section 8e row 4): pass k + 1 filters what pass k wrote, so the rows next to a shard edge depend on the neighbour's pass-k edge rows
+// -- ONE halo exchange per pass.  Pass 1 exchanges an RGB row and runs the fused kernel (the luma plane is dead after it, as in
+// gh_pipeline_gray_sobel_dev); pass k > 1 forms lum(e, e, e) of its own edge rows (not the identity: 13 grey levels move in IEEE mode),
+// exchanges one luma row and runs the plane Sobel.  img_buf: rows + 2 rows of width * channels bytes (rows 1..rows = the shard, in
+// place like the reference); gray_ws: (rows + 2) * width bytes; edge_ws: rows * width bytes (holds the last pass's edge plane on return).
+int gh_sharded_pipeline_gray_sobel_dev(gh_comm_t comm, uint8_t *img_buf, int width, int rows, int channels, int passes, int mode,
+                                       uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    if (passes < 1) passes = 1;   // main_with_sobel.c:44-45
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(img_buf && gray_ws && edge_ws, "null pointer");
+    const size_t npix = (size_t)width * rows, pitch = (size_t)width * channels;
+    uint8_t *shard = img_buf + pitch, *gray = gray_ws + width;
+    for (int p = 0; p < passes; ++p) {
+        int rc;
+        if (p == 0 && channels >= 3) {
+            if ((rc = gh_sharded_fused_step_dev(comm, img_buf, edge_ws, width, rows, channels, mode, stream))) return rc;
+            continue;
+        } else if (p == 0) {
+            rc = gh_gray_rgb8_to_plane_dev(shard, gray, npix, channels, mode, stream);      // channels 1 / 2: the plane is channel 0
+        } else if (channels >= 3) {
+            rc = gh_gray_of_plane_dev(edge_ws, gray, npix, mode, stream);
+        } else {
+            hipError_t e = hipMemcpyAsync(gray, edge_ws, npix, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            rc = e == hipSuccess ? GH_OK : gh_set_error(GH_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+        if (rc) return rc;
+        if ((rc = gh_sharded_sobel_step_dev(comm, gray_ws, edge_ws, width, rows, stream))) return rc;
+    }
+    return gh_replicate_plane_dev(edge_ws, shard, npix, channels, stream);
 }
 
 }  // extern "C"

@@ -23,7 +23,9 @@ constexpr int BLOCK = 256;
 
 struct Taps { int k[9]; int norm; };
 
-__global__ __launch_bounds__(BLOCK) void k_conv3x3_px(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, Taps t)
+// ylo / yhi: first and last readable input row relative to the band's first row (-1 / h where a real halo row lies beyond the band's
+// edge -- row sharding --, 0 / h - 1 where the band edge is the frame border and the row beyond it is the zero border).
+__global__ __launch_bounds__(BLOCK) void k_conv3x3_px(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, int ylo, int yhi, Taps t)
 {
     const size_t rowb = (size_t)w * 3;
     const size_t n = rowb * h;
@@ -35,12 +37,12 @@ __global__ __launch_bounds__(BLOCK) void k_conv3x3_px(const uint8_t *__restrict_
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
             const int yy = y + di - 1;
-            if (yy < 0 || yy >= h) continue;
+            if (yy < ylo || yy > yhi) continue;
 #pragma unroll
             for (int dj = 0; dj < 3; ++dj) {
                 const int xx = xb + 3 * (dj - 1);
                 if (xx < 0 || xx >= (int)rowb) continue;
-                acc += (int)src[(size_t)yy * rowb + xx] * t.k[di * 3 + dj];
+                acc += (int)src[(ptrdiff_t)yy * (ptrdiff_t)rowb + xx] * t.k[di * 3 + dj];
             }
         }
         acc /= t.norm;
@@ -59,7 +61,7 @@ struct TapsF { float k[9]; float inv, half_inv; };
 
 template <int R, int C>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                                      int wb, int h, int groups_x, int order, TapsF t)
+                                                                      int wb, int h, int ylo, int yhi, int groups_x, int order, TapsF t)
 {
     using namespace stream_core;
     constexpr int NROWS = R + 2;
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
             const int yy = y0 - 1 + ch * C + j;
             q[j] = make_uint4(0, 0, 0, 0);
             hb[j] = 0;
-            if (yy >= 0 && yy < h) {                       // rows outside the frame are zeros (zero border)
-                const uint8_t *rowp = src + (size_t)yy * wb;
+            if (yy >= ylo && yy <= yhi) {                  // rows outside the frame are zeros (zero border)
+                const uint8_t *rowp = src + (ptrdiff_t)yy * wb;
                 if (full || in_frame) q[j] = load_stream(reinterpret_cast<const uint4 *>(rowp + x));
                 if (hvalid) hb[j] = *reinterpret_cast<const uint32_t *>(rowp + hxb);
             }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
 // REG = 1: regular bands (every band R + 2 input rows in whole chunks of 6: the branch-free form of k_sobel_dma2 / k_sobel_dma).
 template <int D, int UNAL, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int wb, int h,
-                                                                   int groups_x, stream_core::BandPlan plan, TapsF t)
+                                                                   int ylo, int yhi, int groups_x, stream_core::BandPlan plan, TapsF t)
 {
     using namespace stream_core;
     constexpr int PRE = UNAL ? 16 : 0;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
 
     auto strip_row = [&](int i) {                                // first byte of the strip in band row i, clamped into the frame (wave-uniform)
         int yy = y0 - 1 + i;
-        yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        yy = yy < ylo ? ylo : (yy > yhi ? yhi : yy);
         return uniform_ptr(src + (ptrdiff_t)yy * wb + xw);
     };
     auto issue_row = [&](int i, int slot) {
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
         if (lane == 0 && nl < 3) ql = nl == 0 ? 0u : ql & (~0u << (8 * (4 - nl)));
         if (lane == 63 && nr < 3) qr = nr <= 0 ? 0u : qr & (~0u >> (8 * (4 - nr)));
         const int yin = y0 - 1 + i;
-        if (yin < 0 || yin >= h) { q = make_uint4(0, 0, 0, 0); ql = 0; qr = 0; }
+        if (yin < ylo || yin > yhi) { q = make_uint4(0, 0, 0, 0); ql = 0; qr = 0; }
         // p[-3..18] as floats; pair layout G[m] = (p[m-3], p[m+5]), m = 0..13
         const uint32_t wv[6] = {ql, q.x, q.y, q.z, q.w, qr};                   // wv[0] bytes = p[-4..-1]
         f32x2 G[14];
@@ -330,8 +332,11 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
 
 }  // namespace
 
-extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height, const int32_t kernel[9], int32_t norm,
-                                   gh_stream_t stream)
+// Band form (row sharding): `height` output rows starting at src / dst; where an edge of the band is not the
+// frame border the input row beyond it (src - pitch / src + height * pitch) is a real row of the frame -- a halo row received from
+// the neighbouring rank -- instead of the zero border.  The whole-frame entry point is the band with both edges on the border.
+extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int height, const int32_t kernel[9], int32_t norm,
+                                        int top_is_border, int bottom_is_border, gh_stream_t stream)
 {
     GH_REQUIRE(width >= 0 && height >= 0, "negative size");
     GH_REQUIRE(kernel, "null kernel");
@@ -348,6 +353,7 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
     const long long wb = (long long)width * 3;
     const bool exact = (long long)sgn * norm <= 4096 && ksum * 255 < (1ll << 24) && !getenv("GH_CONV_IMPL");     // conditions of the f32 forms
     const bool aligned = (wb % 16 == 0) && gh_aligned16(src) && gh_aligned16(dst);
+    const int ylo = top_is_border ? 0 : -1, yhi = bottom_is_border ? height - 1 : height;   // readable input rows, relative to the band
     TapsF t;
     for (int i = 0; i < 9; ++i) t.k[i] = (float)(sgn * kernel[i]);
     {
@@ -376,12 +382,12 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
                          !stream_core::shifted_band_overflows(groups_x, height, R, 5, GH_NUM_CU);
         gh_note_kernel(reg ? (unal ? "k_conv3x3_dma regular unaligned" : "k_conv3x3_dma regular") : (unal ? "k_conv3x3_dma unaligned" : "k_conv3x3_dma"));
-        if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
-        else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
-        else if (reg) k_conv3x3_dma<3, 2, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
-        else if (unal == 0) k_conv3x3_dma<3, 0><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
-        else if (unal == 1) k_conv3x3_dma<3, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
-        else k_conv3x3_dma<3, 2><<<g, b, 0, s>>>(src, dst, (int)wb, height, groups_x, plan, t);
+        if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
+        else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
+        else if (reg) k_conv3x3_dma<3, 2, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
+        else if (unal == 0) k_conv3x3_dma<3, 0><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
+        else if (unal == 1) k_conv3x3_dma<3, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
+        else k_conv3x3_dma<3, 2><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
         GH_LAUNCH_CHECK();
         return GH_OK;
     }
@@ -402,17 +408,23 @@ extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, 
         plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x);   // band-per-XCD, as the fused kernel
         const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
-        else if (R == 32) k_conv3x3_stream<32, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
-        else k_conv3x3_stream<16, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, groups_x, plan.order, t);
+        if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan.order, t);
+        else if (R == 32) k_conv3x3_stream<32, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan.order, t);
+        else k_conv3x3_stream<16, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan.order, t);
     } else {
         Taps t;
         for (int i = 0; i < 9; ++i) t.k[i] = kernel[i];
         t.norm = norm;
         size_t blocks = ((size_t)width * height * 3 + BLOCK - 1) / BLOCK;
         if (blocks > (1u << 20)) blocks = 1u << 20;
-        k_conv3x3_px<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, height, t);
+        k_conv3x3_px<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, height, ylo, yhi, t);
     }
     GH_LAUNCH_CHECK();
     return GH_OK;
+}
+
+extern "C" int gh_conv3x3_rgb8_dev(const uint8_t *src, uint8_t *dst, int width, int height, const int32_t kernel[9], int32_t norm,
+                                   gh_stream_t stream)
+{
+    return gh_conv3x3_rgb8_rows_dev(src, dst, width, height, kernel, norm, 1, 1, stream);
 }

@@ -139,10 +139,19 @@ def _long_array(a, shape) -> np.ndarray:
     return a
 
 
+def _rgb_long_array(a) -> np.ndarray:
+    """(rows, cols, 3) longs: the kernels read three longs per pixel and the pointer trees are built with 24-byte cells."""
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise GrayHipError(f"expected a (rows, cols, 3) array, got shape {a.shape}")
+    return a
+
+
 def old_parallel_convolution(img_padded, kernel, convolved_img: np.ndarray, gblur_norm: int) -> np.ndarray:
     """old/parallel_convolution.c:8 -- img_padded (rows+2, cols+2, 3) longs, kernel 3x3 longs; the weighted sums are ADDED to
     convolved_img (rows, cols, 3) int64 and divided by gblur_norm in place."""
-    if convolved_img.dtype != np.int64 or not convolved_img.flags["C_CONTIGUOUS"] or convolved_img.ndim != 3:
+    if (not isinstance(convolved_img, np.ndarray) or convolved_img.dtype != np.int64 or not convolved_img.flags["C_CONTIGUOUS"]
+            or convolved_img.ndim != 3 or convolved_img.shape[2] != 3):
         raise GrayHipError("convolved_img must be a C-contiguous (rows, cols, 3) int64 array")
     rows, cols = convolved_img.shape[:2]
     img = _long_array(img_padded, (rows + 2, cols + 2, 3))
@@ -156,7 +165,7 @@ def old_parallel_convolution(img_padded, kernel, convolved_img: np.ndarray, gblu
 
 def old_parallel_avg_pixel(img, avgs_in=(0, 0, 0)) -> list:
     """old/parallel_avg_pixel.c:5 -- avgs = (avgs_in + 3 * sum) / (rows * cols * 3)."""
-    img = np.ascontiguousarray(img, dtype=np.int64)
+    img = _rgb_long_array(img)
     rows, cols = img.shape[:2]
     avgs = np.asarray(avgs_in, dtype=np.int64).copy()
     check(abi.load().gh_old_parallel_avg_pixel(img.ctypes.data, avgs.ctypes.data_as(C.POINTER(C.c_long)), rows, cols), "parallel_avg_pixel")
@@ -165,7 +174,7 @@ def old_parallel_avg_pixel(img, avgs_in=(0, 0, 0)) -> list:
 
 def old_parallel_to_grayscale(img):
     """old/parallel_to_grayscale.c:7 -- returns ((rows, cols, 3) int64 grey image, [min, max])."""
-    img = np.ascontiguousarray(img, dtype=np.int64)
+    img = _rgb_long_array(img)
     rows, cols = img.shape[:2]
     out = np.zeros((rows, cols, 3), dtype=np.int64)
     mm = np.zeros(2, dtype=np.int64)
@@ -298,6 +307,19 @@ def conv3x3(rgb, kernel, norm: int, out=None):
     return out
 
 
+def conv3x3_rows(buf, out, rows: int, kernel, norm: int, top_is_border: bool, bottom_is_border: bool):
+    """Band form of the 3x3 convolution: `buf` is (rows+2, w, 3) with RGB halo rows 0 and rows+1 (ignored where the band edge is the
+    frame border: the zero border applies there); `out` is (rows, w, 3)."""
+    w, c = buf.shape[1], buf.shape[2]
+    if c != 3:
+        raise GrayHipError("conv3x3 takes RGB8 frames")
+    assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w, 3)
+    k = (C.c_int32 * 9)(*[int(v) for v in np.asarray(kernel).reshape(-1)])
+    check(abi.load().gh_conv3x3_rgb8_rows_dev(_dev_ptr(buf) + w * 3, _dev_ptr(out), w, rows, k, int(norm), int(top_is_border),
+                                              int(bottom_is_border), _stream()), "conv3x3_rows")
+    return out
+
+
 def sum_rgb_dev(rgb):
     """Device-resident exact channel sums -> python ints."""
     import torch
@@ -306,13 +328,22 @@ def sum_rgb_dev(rgb):
     return [int(v) for v in sums.cpu().tolist()]
 
 
-def mean_gray_minmax(rgb, out=None):
+def mean_gray_minmax_dev(rgb, out=None, minmax=None):
+    """g = (r+g+b)/3 replicated; returns (out, minmax) with minmax a device int32[2] = {min, max} (initialised to the reference's
+    256 / -1 when not given: old/parallel_to_grayscale.c:9-10) -- the form the sharded reduction consumes without a host round trip."""
     import torch
     if out is None:
         out = torch.empty_like(rgb)
-    mm = torch.tensor([256, -1], dtype=torch.int32, device=rgb.device)
-    check(abi.load().gh_mean_gray_minmax_dev(_dev_ptr(rgb), _dev_ptr(out), rgb.numel() // 3, mm.data_ptr(), _stream()),
-          "mean_gray_minmax")
+    if minmax is None:
+        minmax = torch.tensor([256, -1], dtype=torch.int32, device=rgb.device)
+    if rgb.numel():
+        check(abi.load().gh_mean_gray_minmax_dev(_dev_ptr(rgb), _dev_ptr(out), rgb.numel() // 3, minmax.data_ptr(), _stream()),
+              "mean_gray_minmax")
+    return out, minmax
+
+
+def mean_gray_minmax(rgb, out=None):
+    out, mm = mean_gray_minmax_dev(rgb, out)
     lo, hi = mm.cpu().tolist()
     return out, int(lo), int(hi)
 

@@ -9,7 +9,11 @@ the 8 GPUs of a node:
 * Sobel (monolithic/src/sobel.c:10-24) needs one luma row from each neighbour: a `width`-byte
   send/recv pair per neighbour (RCCL ncclSend/ncclRecv via torch.distributed P2P, grouped in one
   batch), overlapped with the interior rows, which do not depend on the halo;
-* the channel sums (old/parallel_avg_pixel.c) are partial sums + one 24-byte all-reduce.
+* the 3x3 convolution (old/parallel_convolution.c:8-24) needs one RGB row from each neighbour, the same exchange step;
+* the multi-pass gray+Sobel pipeline (monolithic/src/main_with_sobel.c:49-76) needs that exchange once PER PASS: pass k+1
+  filters what pass k wrote, so a shard's edge rows depend on the neighbours' pass-k edge rows;
+* the channel sums (old/parallel_avg_pixel.c) are partial sums + one 24-byte all-reduce, the mean-grey min / max
+  (old/parallel_to_grayscale.c:12,36-37) one min and one max all-reduce of an int32.
 
 The pixel work is delegated to a `backend` object so the same code runs on the GPU (HipBackend ->
 libgrayhip.so, the product path) and, in the CPU test-suite only, on a checker backend over gloo.
@@ -53,6 +57,22 @@ class HipBackend:
 
     def sum_rgb(self, rgb):
         return self.api.sum_rgb_dev(rgb)
+
+    def conv_rows(self, buf, out, rows, kernel, norm, top_is_border, bottom_is_border):
+        return self.api.conv3x3_rows(buf, out, rows, kernel, norm, top_is_border, bottom_is_border)
+
+    def gray_of_plane(self, plane, out):
+        return self.api.gray_of_plane(plane, self.mode, out=out)
+
+    def replicate_plane(self, plane, img):
+        return self.api.replicate_plane(plane, img)
+
+    def extract_plane(self, img, out):
+        return self.api.extract_plane(img, out=out)
+
+    def mean_gray_minmax(self, rgb, out):
+        """-> (min, max) of the shard as a device int32[2] tensor (256 / -1 for an empty shard)."""
+        return self.api.mean_gray_minmax_dev(rgb, out)[1]
 
     # Pre-bound launchers: at 8 GPUs a shard's kernels take ~30 us, so per-step Python overhead matters.
     # Pointers, sizes and flags are resolved once; the returned closure is one ctypes call.
@@ -132,6 +152,34 @@ class NativeHaloComm:
     def allreduce_sum_u64(self, t, stream):
         self.abi.check(self.lib.gh_comm_allreduce_sum_u64_dev(self.handle, t.data_ptr(), t.numel(), stream), "gh_comm_allreduce_sum_u64_dev")
 
+    def allreduce_minmax_i32(self, t, stream):
+        """t: device int32[2] = {min, max}; in place min / max over all ranks (gh_comm_allreduce_minmax_i32_dev)."""
+        import torch
+        assert t.dtype == torch.int32 and t.numel() == 2 and t.is_contiguous()
+        self.abi.check(self.lib.gh_comm_allreduce_minmax_i32_dev(self.handle, t.data_ptr(), stream), "gh_comm_allreduce_minmax_i32_dev")
+
+    def exchange_count(self) -> int:
+        """Halo-row ncclGroups issued so far (one per sharded step, one per batch of prefetched frames)."""
+        return int(self.lib.gh_comm_exchange_count(self.handle))
+
+    def bind_conv_step(self, rgb_buf, out, rows, kernel, norm):
+        import ctypes as C
+        import torch
+        w = rgb_buf.shape[1]
+        assert tuple(rgb_buf.shape) == (rows + 2, w, 3) and tuple(out.shape) == (rows, w, 3) and rgb_buf.is_contiguous() and out.is_contiguous()
+        k = (C.c_int32 * 9)(*[int(v) for v in kernel])
+        fn, chk, h, src, dst, norm = self.lib.gh_sharded_conv3x3_step_dev, self.abi.check, self.handle, rgb_buf.data_ptr(), out.data_ptr(), int(norm)
+        return lambda: chk(fn(h, src, dst, w, rows, k, norm, torch.cuda.current_stream().cuda_stream), "gh_sharded_conv3x3_step_dev")
+
+    def bind_pipeline_gray_sobel(self, img_buf, gray_ws, edge_ws, rows, passes, mode):
+        import torch
+        w, c = img_buf.shape[1], img_buf.shape[2]
+        assert img_buf.shape[0] == rows + 2 and tuple(gray_ws.shape) == (rows + 2, w) and tuple(edge_ws.shape) == (rows, w)
+        assert img_buf.is_contiguous() and gray_ws.is_contiguous() and edge_ws.is_contiguous()
+        fn, chk, h = self.lib.gh_sharded_pipeline_gray_sobel_dev, self.abi.check, self.handle
+        img, g, e = img_buf.data_ptr(), gray_ws.data_ptr(), edge_ws.data_ptr()
+        return lambda: chk(fn(h, img, w, rows, c, passes, mode, g, e, torch.cuda.current_stream().cuda_stream), "gh_sharded_pipeline_gray_sobel_dev")
+
     def bind_fused_step(self, rgb_buf, edge, rows, mode):
         import torch
         w, c = rgb_buf.shape[1], rgb_buf.shape[2]
@@ -173,10 +221,17 @@ class NativeHaloComm:
         groups = [(C.c_void_p * batch)(*[ptrs[(g * batch + i) % n] for i in range(batch)]) for g in range(n // batch)]
         row_bytes = w * c
 
+        requested = [-1]     # the group whose halos the last batch request covered
+
         def fn(k):
             s = torch.cuda.current_stream().cuda_stream
-            if k % batch == 0:                        # the frames of the batch AFTER this one
-                chk(pre(h, groups[((k // batch) + 1) % len(groups)], batch, row_bytes, rows, s), "gh_sharded_prefetch_halos_dev")
+            if k % batch == 0:
+                g = (k // batch) % len(groups)
+                if requested[0] != g:                 # cold start, or the caller restarted its step counter: this batch's own halos first
+                    chk(pre(h, groups[g], batch, row_bytes, rows, s), "gh_sharded_prefetch_halos_dev")
+                nxt = (g + 1) % len(groups)           # the frames of the batch AFTER this one travel while this one is processed
+                chk(pre(h, groups[nxt], batch, row_bytes, rows, s), "gh_sharded_prefetch_halos_dev")
+                requested[0] = nxt
             chk(step(h, ptrs[k % n], None, dst, w, rows, c, mode, s), "gh_sharded_fused_step_pipelined_dev")
         return fn
 
@@ -223,7 +278,15 @@ class ShardGeometry:
 
     @property
     def top_is_border(self) -> bool:
-        return self.rank == 0
+        # the first rank WITH rows owns the frame's top edge: row_partition gives the remainder to the last ranks, so when the frame
+        # has fewer rows than there are ranks the empty shards are the leading ones (and take part in no exchange)
+        return self.y0 == 0
+
+    @property
+    def has_empty_shards(self) -> bool:
+        """True on every rank alike iff some rank of the partition has no rows (frame height < world).  The C++ step functions
+        address their neighbours as rank -/+ 1 and are not used then; the torch.distributed path skips the empty ranks."""
+        return self.rows == 0 if self.rank == 0 else self.y0 < self.rank
 
     @property
     def bottom_is_border(self) -> bool:
@@ -252,7 +315,7 @@ class ShardedGraySobel:
         b, g = backend, geom
         if rows == 0:
             return
-        if native_comm is not None and g.world > 1:
+        if native_comm is not None and g.world > 1 and not g.has_empty_shards:
             assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
             self._native = native_comm.bind_sobel_step(self.luma, self.edge, rows)
             return
@@ -336,7 +399,7 @@ class ShardedFusedGraySobel:
         b, g = backend, geom
         if rows == 0:
             return
-        if native_comm is not None and g.world > 1:
+        if native_comm is not None and g.world > 1 and not g.has_empty_shards:
             assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
             self._native = native_comm.bind_fused_step(self.rgb, self.edge, rows, getattr(backend, "mode", 0))
             return
@@ -402,3 +465,132 @@ def allreduce_channel_sums(local_sums, device, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return [int(v) for v in t.cpu().tolist()]
+
+
+def allreduce_minmax(local_minmax, device, group=None, native_comm=None):
+    """Global (min, max) of the mean-grey levels from per-shard (min, max): `reduction(min:) reduction(max:)` of
+    old/parallel_to_grayscale.c:12 across ranks.  local_minmax: a device int32[2] tensor (HipBackend.mean_gray_minmax) or a pair
+    of ints; a rank without rows passes the reference's initial values (256, -1), the neutral elements."""
+    import torch
+    import torch.distributed as dist
+    t = local_minmax if isinstance(local_minmax, torch.Tensor) else torch.tensor([int(local_minmax[0]), int(local_minmax[1])], dtype=torch.int32, device=device)
+    if native_comm is not None:
+        native_comm.allreduce_minmax_i32(t, torch.cuda.current_stream().cuda_stream)
+    elif dist.is_initialized() and dist.get_world_size(group) > 1:
+        lo, hi = t[0:1].clone(), t[1:2].clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        t = torch.cat([lo, hi])
+    lo, hi = t.cpu().tolist()
+    return int(lo), int(hi)
+
+
+class _RowHalo:
+    """The exchange step shared by the sharded operators below: row 1 of `buf` goes to the rank above and its last row arrives in
+    row 0; row `rows` goes down and the lower neighbour's first row arrives in row rows+1 (torch.distributed P2P ops, one batch)."""
+
+    def __init__(self, geom: ShardGeometry, buf, group=None):
+        self.g, self.buf, self.group, self._ops = geom, buf, group, None
+
+    def __call__(self):
+        import torch.distributed as dist
+        g, buf = self.g, self.buf
+        if g.world == 1 or g.rows == 0:
+            return
+        if self._ops is None:
+            ops = []
+            if not g.top_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[1], g.rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[0], g.rank - 1, self.group))
+            if not g.bottom_is_border:
+                ops.append(dist.P2POp(dist.isend, buf[g.rows], g.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
+            self._ops = ops
+        for wk in (dist.batch_isend_irecv(self._ops) if self._ops else []):
+            wk.wait()
+
+
+class ShardedConv3x3:
+    """One rank's share of the 3x3 convolution (old/parallel_convolution.c:8-24) on a row-sharded RGB8 frame: `rgb` is
+    (rows+2, width, 3), rows 1..rows = the shard; per step one RGB row is exchanged with each neighbour, then ONE launch
+    covers the shard.  The frame's own top / bottom edge keeps the zero border.  step() returns `out` (rows, width, 3)."""
+
+    def __init__(self, geom: ShardGeometry, backend, device, kernel, norm: int, group=None, native_comm=None):
+        import torch
+        self.g, self.backend = geom, backend
+        self.kernel, self.norm = [int(v) for v in kernel], int(norm)
+        rows = geom.rows
+        self.rgb = torch.zeros((rows + 2, geom.width, 3), dtype=torch.uint8, device=device)
+        self.out = torch.empty((rows, geom.width, 3), dtype=torch.uint8, device=device)
+        self._native = None
+        if rows and native_comm is not None and geom.world > 1 and not geom.has_empty_shards:
+            assert (native_comm.rank, native_comm.world) == (geom.rank, geom.world)
+            self._native = native_comm.bind_conv_step(self.rgb, self.out, rows, self.kernel, self.norm)
+        self._halo = _RowHalo(geom, self.rgb, group)
+
+    @property
+    def shard(self):
+        return self.rgb[1:self.g.rows + 1]
+
+    def step(self):
+        g = self.g
+        if g.rows == 0:
+            return self.out
+        if self._native is not None:
+            self._native()
+            return self.out
+        self._halo()
+        self.backend.conv_rows(self.rgb, self.out, g.rows, self.kernel, self.norm, g.top_is_border, g.bottom_is_border)
+        return self.out
+
+
+class ShardedPipelineGraySobel:
+    """One rank's share of the reference's multi-pass driver loop -- `passes` x (gray, extract, Sobel, replicate),
+    monolithic/src/main_with_sobel.c:49-76 -- on a row-sharded frame, in place in `img` (rows+2, width, channels; rows
+    1..rows = the shard).  Pass k+1 filters what pass k wrote, so there is ONE halo exchange per pass: an RGB row before pass 1
+    (the fused kernel recomputes the halo luma), the luma row lum(e, e, e) of the neighbours' edge rows before every later pass
+    (not the identity: 13 grey levels move in IEEE mode).  run(passes) returns the last pass's edge plane (rows, width)."""
+
+    def __init__(self, geom: ShardGeometry, backend, device, channels: int = 3, group=None, native_comm=None):
+        import torch
+        self.g, self.backend, self.channels = geom, backend, channels
+        rows = geom.rows
+        self.img = torch.zeros((rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
+        self.gray = torch.zeros((rows + 2, geom.width), dtype=torch.uint8, device=device)
+        self.edge = torch.zeros((rows, geom.width), dtype=torch.uint8, device=device)
+        self._native_comm = native_comm if (rows and native_comm is not None and geom.world > 1 and not geom.has_empty_shards) else None
+        self._native = {}
+        self._halo_img = _RowHalo(geom, self.img, group)
+        self._halo_gray = _RowHalo(geom, self.gray, group)
+
+    @property
+    def shard(self):
+        return self.img[1:self.g.rows + 1]
+
+    def run(self, passes: int = 1):
+        g, b, rows = self.g, self.backend, self.g.rows
+        passes = max(int(passes), 1)              # main_with_sobel.c:44-45
+        if rows == 0:                             # an empty (leading) shard takes part in no exchange: ShardGeometry.top_is_border
+            return self.edge
+        if self._native_comm is not None:
+            fn = self._native.get(passes)
+            if fn is None:
+                fn = self._native[passes] = self._native_comm.bind_pipeline_gray_sobel(self.img, self.gray, self.edge, rows, passes, getattr(b, "mode", 0))
+            fn()
+            return self.edge
+        luma = self.gray[1:rows + 1]
+        for p in range(passes):
+            if p == 0 and self.channels >= 3:
+                self._halo_img()
+                b.fused_rows(self.img, self.edge, rows, g.top_is_border, g.bottom_is_border)
+                continue
+            if p == 0:
+                b.extract_plane(self.shard, luma)                 # channels 1 / 2: the plane is channel 0
+            elif self.channels >= 3:
+                b.gray_of_plane(self.edge, luma)
+            else:
+                luma.copy_(self.edge)
+            self._halo_gray()
+            b.sobel_rows(self.gray, self.edge, rows, g.top_is_border, g.bottom_is_border)
+        b.replicate_plane(self.edge, self.shard)
+        return self.edge

@@ -95,3 +95,18 @@ def test_product_path_never_imports_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", os.path.join(pkgdir, "lib", "libgrayhip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "libref" not in out
+
+
+def test_historic_wrappers_refuse_frames_that_are_not_three_channel(pkg):
+    """The old/ entry points read three longs per pixel and the pointer trees are built with 24-byte cells: any other trailing
+    dimension is refused before anything reaches the library (no GPU needed to see that)."""
+    api = pkg.hostapi
+    for bad in (np.zeros((4, 5, 4), np.int64), np.zeros((4, 5), np.int64), np.zeros((4, 5, 1), np.int64)):
+        with pytest.raises(pkg.GrayHipError):
+            api.old_parallel_avg_pixel(bad)
+        with pytest.raises(pkg.GrayHipError):
+            api.old_parallel_to_grayscale(bad)
+    with pytest.raises(pkg.GrayHipError):
+        api.old_parallel_convolution(np.zeros((6, 7, 3), np.int64), [1] * 9, np.zeros((4, 5, 4), np.int64), 9)
+    with pytest.raises(pkg.GrayHipError):
+        api.old_parallel_convolution(np.zeros((6, 7, 4), np.int64), [1] * 9, np.zeros((4, 5, 3), np.int64), 9)

@@ -1,0 +1,241 @@
+"""SURVEY.md section 8(e), the rows beyond Sobel / fused: the 3x3 convolution on a row band and on a shard, the multi-pass
+gray+Sobel pipeline on a shard (one halo exchange per pass), the min / max reduction across ranks, and the bookkeeping of
+the batched halo prefetch.  One GPU: row bands against the whole frame, and libgrayhip's own RCCL communicator in loopback
+mode (both neighbours of the shard are the shard itself: real ncclSend / ncclRecv, the halo rows become copies of the
+shard's own first / last row).  The exchange protocol across ranks is covered with gloo in tests/test_sharding_gloo.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAUSS, BOX, SIGNED, SHARPEN = [1, 2, 1, 2, 4, 2, 1, 2, 1], [1] * 9, [-1, -2, -1, 0, 0, 0, 1, 2, 1], [0, -1, 0, -1, 5, -1, 0, -1, 0]
+
+
+@pytest.fixture(scope="module")
+def torch_mod(pkg):
+    import torch
+    pkg.hostapi.init(0)
+    return torch
+
+
+@pytest.fixture(scope="module")
+def native_comm(pkg, torch_mod):
+    comm = pkg.sharding.NativeHaloComm(0, 1)
+    yield comm
+    comm.close()
+
+
+def dev(torch, a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- old/parallel_convolution.c:8-24 on row bands --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("w,h,parts", [(1024, 96, 3), (2048, 67, 2), (48, 10, 4), (342, 40, 3), (683, 33, 5), (1366, 50, 4), (5461, 36, 2), (352, 64, 8), (16, 3, 3)])
+def test_conv_row_bands_equal_whole_frame(pkg, oracle, torch_mod, w, h, parts, monkeypatch):
+    """gh_conv3x3_rgb8_rows_dev on the bands of a partition == the whole-frame operator == the oracle: a band edge inside the frame
+    reads the real row beyond it, an edge on the frame border the zero border.  Widths for every kernel form (LDS-DMA ring aligned /
+    dword-shifted / byte-realigned, register-staged strips, per-pixel), bands of one row included."""
+    t = torch_mod
+    sharding = pkg.sharding
+    img = oracle.frame_rand(w, h, 3, seed=3 * w + h)
+    full = dev(t, img)
+    for kern, norm in ((GAUSS, 16), (SIGNED, 3), ([3, 1, 4, 1, 5, 9, 2, 6, 5], 36)):
+        want = oracle.conv3x3(img, kern, norm)
+        for knobs in ({}, {"GH_CONV_DMA": "0"}, {"GH_CONV_IMPL": "px"}):
+            for k_, v_ in knobs.items():
+                monkeypatch.setenv(k_, v_)
+            got = t.full((h, w, 3), 0x5A, dtype=t.uint8, device="cuda")
+            for y0, y1 in sharding.row_partition(h, parts):
+                if y1 == y0:
+                    continue
+                top, bot = y0 == 0, y1 == h
+                # the band in a buffer of its own with its halo rows (poisoned where the band edge is the frame border: must not be read)
+                buf = t.full((y1 - y0 + 2, w, 3), 0xEE, dtype=t.uint8, device="cuda")
+                buf[1:y1 - y0 + 1] = full[y0:y1]
+                if not top:
+                    buf[0] = full[y0 - 1]
+                if not bot:
+                    buf[y1 - y0 + 1] = full[y1]
+                pkg.hostapi.conv3x3_rows(buf, got[y0:y1], y1 - y0, kern, norm, top, bot)
+            assert np.array_equal(got.cpu().numpy(), want), (kern, norm, knobs)
+            for k_ in knobs:
+                monkeypatch.delenv(k_)
+
+
+def _replicate_padded(img):
+    return np.concatenate([img[:1], img, img[-1:]], axis=0)
+
+
+@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (342, 17), (5464, 2), (4099, 35), (64, 1)])
+def test_native_sharded_conv_step_loopback(pkg, oracle, native_comm, torch_mod, w, h):
+    """gh_sharded_conv3x3_step_dev as a middle shard whose neighbours are itself: the halo rows become copies of the shard's own
+    first and last RGB row, so the result equals the oracle on the frame padded by replicating those rows (left / right: zero border)."""
+    t = torch_mod
+    img = oracle.frame_rand(w, h, 3, seed=w * 11 + h)
+    native_comm.set_loopback(True)
+    try:
+        for kern, norm in ((GAUSS, 16), (BOX, 9), (SHARPEN, 1)):
+            want = oracle.conv3x3(_replicate_padded(img), kern, norm)[1:-1]
+            buf = t.full((h + 2, w, 3), 0x77, dtype=t.uint8, device="cuda")
+            buf[1:h + 1] = dev(t, img)
+            out = t.full((h, w, 3), 9, dtype=t.uint8, device="cuda")
+            step = native_comm.bind_conv_step(buf, out, h, kern, norm)
+            n0 = native_comm.exchange_count()
+            step()
+            step()                      # the second step's exchange must wait for the first step's reads of the halo rows
+            t.cuda.synchronize()
+            assert native_comm.exchange_count() - n0 == 2
+            assert np.array_equal(buf[0].cpu().numpy(), img[0]) and np.array_equal(buf[h + 1].cpu().numpy(), img[-1])
+            assert np.array_equal(out.cpu().numpy(), want), (kern, norm)
+        # through the runner class, as bench / applications use it (world 1 -> plain launch, no exchange: zero border all round)
+        geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
+        runner = pkg.sharding.ShardedConv3x3(geom, pkg.sharding.HipBackend(0), "cuda", GAUSS, 16)
+        runner.shard.copy_(dev(t, img))
+        assert np.array_equal(runner.step().cpu().numpy(), oracle.conv3x3(img, GAUSS, 16))
+    finally:
+        native_comm.set_loopback(False)
+
+
+# ---- monolithic/src/main_with_sobel.c:49-76 on a shard: one halo exchange per pass ------------------------------------------
+
+def _loopback_multipass(oracle, img, passes, mode):
+    """What a middle shard whose neighbours are itself must produce: before every pass the rows above / below the shard are copies
+    of the shard's own first / last row of that pass's input plane."""
+    h, w, c = img.shape
+
+    def sobel_padded(plane):
+        e = oracle.sobel(_replicate_padded(plane))[1:-1].copy()
+        e[:, 0] = 0
+        e[:, -1] = 0
+        return e
+
+    edge = None
+    for p in range(passes):
+        if p == 0:
+            plane = oracle.gray_to_plane(img, mode)
+        elif c >= 3:
+            plane = oracle.gray_to_plane(np.repeat(edge[:, :, None], 3, axis=2), mode)       # lum(e, e, e): not the identity
+        else:
+            plane = edge
+        edge = sobel_padded(plane)
+    out = img.copy()
+    out[:, :, :(3 if c >= 3 else 1)] = edge[:, :, None]
+    return out, edge
+
+
+@pytest.mark.parametrize("w,h,c", [(1024, 40, 3), (2064, 5, 3), (333, 77, 4), (4096, 3, 3), (1031, 33, 3), (64, 9, 1), (16384, 66, 3)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_native_sharded_multipass_pipeline_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, mode):
+    t = torch_mod
+    img = oracle.frame_rand(w, h, c, seed=w + 13 * h + c)
+    native_comm.set_loopback(True)
+    try:
+        for passes in (1, 2, 3):
+            want_img, want_edge = _loopback_multipass(oracle, img, passes, mode)
+            buf = t.full((h + 2, w, c), 0x66, dtype=t.uint8, device="cuda")
+            buf[1:h + 1] = dev(t, img)
+            gray = t.full((h + 2, w), 0x55, dtype=t.uint8, device="cuda")
+            edge = t.full((h, w), 0x44, dtype=t.uint8, device="cuda")
+            run = native_comm.bind_pipeline_gray_sobel(buf, gray, edge, h, passes, mode)
+            n0 = native_comm.exchange_count()
+            run()
+            t.cuda.synchronize()
+            assert native_comm.exchange_count() - n0 == passes                      # ONE exchange per pass
+            assert np.array_equal(edge.cpu().numpy(), want_edge), passes
+            assert np.array_equal(buf[1:h + 1].cpu().numpy(), want_img), passes     # in place, alpha untouched
+    finally:
+        native_comm.set_loopback(False)
+
+
+@pytest.mark.parametrize("w,h,c,passes", [(1040, 40, 3, 3), (64, 48, 4, 2), (333, 20, 3, 1)])
+def test_unsharded_multipass_runner_equals_the_reference_pipeline(pkg, oracle, native_comm, torch_mod, w, h, c, passes):
+    """world = 1: the sharded pipeline is the whole-frame pipeline (no exchange, frame border on both sides) == the oracle's
+    restatement of main_with_sobel.c:49-76 == gh_pipeline_gray_sobel_dev."""
+    t = torch_mod
+    img = oracle.frame_rand(w, h, c, seed=w + h + c + passes)
+    want_img, _, want_edge = oracle.pipeline(img.copy(), passes, 0)
+    geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
+    pipe = pkg.sharding.ShardedPipelineGraySobel(geom, pkg.sharding.HipBackend(0), "cuda", channels=c)
+    pipe.shard.copy_(dev(t, img))
+    pipe.run(passes)
+    assert np.array_equal(pipe.edge.cpu().numpy(), want_edge) and np.array_equal(pipe.shard.cpu().numpy(), want_img)
+    # the C++ entry point with a world-of-1 communicator takes the same road
+    buf = t.zeros((h + 2, w, c), dtype=t.uint8, device="cuda")
+    buf[1:h + 1] = dev(t, img)
+    gray, edge = t.zeros((h + 2, w), dtype=t.uint8, device="cuda"), t.zeros((h, w), dtype=t.uint8, device="cuda")
+    native_comm.bind_pipeline_gray_sobel(buf, gray, edge, h, passes, 0)()
+    t.cuda.synchronize()
+    assert np.array_equal(edge.cpu().numpy(), want_edge) and np.array_equal(buf[1:h + 1].cpu().numpy(), want_img)
+
+
+# ---- old/parallel_to_grayscale.c:12,36-37: min / max across ranks -----------------------------------------------------------
+
+def test_minmax_allreduce_native(pkg, oracle, native_comm, torch_mod):
+    t = torch_mod
+    img = oracle.frame_rand(1021, 517, 3, seed=1)
+    _, wlo, whi = oracle.mean_gray_minmax(img)
+    backend = pkg.sharding.HipBackend(0)
+    d = dev(t, img)
+    mm = backend.mean_gray_minmax(d, t.empty_like(d))
+    assert mm.dtype == t.int32 and mm.cpu().tolist() == [wlo, whi]
+    # over libgrayhip's communicator (one rank: the identity, but the ncclMin / ncclMax group really runs) ...
+    assert pkg.sharding.allreduce_minmax(mm, "cuda", native_comm=native_comm) == (wlo, whi)
+    # ... partial results of row blocks combine to the frame's, an empty block contributes the neutral 256 / -1
+    parts = [(0, 100), (100, 100), (100, 400), (400, 517)]
+    lo, hi = 256, -1
+    for y0, y1 in parts:
+        blk = d[y0:y1].contiguous()
+        m = backend.mean_gray_minmax(blk, t.empty_like(blk)).cpu().tolist()
+        if y1 == y0:
+            assert m == [256, -1]
+        lo, hi = min(lo, m[0]), max(hi, m[1])
+    assert (lo, hi) == (wlo, whi)
+    raw = t.tensor([7, -3], dtype=t.int32, device="cuda")
+    native_comm.allreduce_minmax_i32(raw, t.cuda.current_stream().cuda_stream)
+    t.cuda.synchronize()
+    assert raw.cpu().tolist() == [7, -3]
+
+
+# ---- batched halo prefetch: one exchange per batch, whatever the batch size and however the caller counts its steps ----------
+
+@pytest.mark.parametrize("batch,nbuf", [(1, 2), (2, 4), (3, 6), (4, 8), (2, 8), (4, 16)])
+def test_batched_prefetch_issues_one_exchange_per_batch(pkg, oracle, native_comm, torch_mod, batch, nbuf):
+    """Round 2's table recycled the event of the batch just requested when the single-request fallback had used up the pool
+    (batches of 3 and 4: every step fell back to an exchange of its own, pixels still right).  Counted here: a pass over the ring
+    issues nbuf / batch group exchanges, plus one for the cold start; a caller that restarts its step counter at 0 (bench.py after
+    its check loop) pays one more, not one per step."""
+    t = torch_mod
+    w, h = 1040, 19
+    native_comm.set_loopback(True)
+    try:
+        frames = [oracle.frame_rand(w, h, 3, seed=900 + s) for s in range(nbuf)]
+        bufs = []
+        for img in frames:
+            b = t.full((h + 2, w, 3), 0x77, dtype=t.uint8, device="cuda")
+            b[1:h + 1] = dev(t, img)
+            bufs.append(b)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+
+        def expected(img):
+            e = oracle.sobel(oracle.gray_to_plane(_replicate_padded(img), 0))[1:-1].copy()
+            e[:, 0] = 0
+            e[:, -1] = 0
+            return e
+
+        step = native_comm.bind_fused_step_batched(bufs, edge, h, 0, batch)
+        n0 = native_comm.exchange_count()
+        for k in range(3 * nbuf):
+            step(k)
+        t.cuda.synchronize()
+        assert native_comm.exchange_count() - n0 == 3 * nbuf // batch + 1
+        assert np.array_equal(edge.cpu().numpy(), expected(frames[(3 * nbuf - 1) % nbuf]))
+        # the counter restarts at 0 while the table still holds the request for the group after the last one processed
+        n1 = native_comm.exchange_count()
+        for k in range(2 * nbuf):
+            step(k)
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[k % nbuf])), k
+        assert native_comm.exchange_count() - n1 <= 2 * nbuf // batch + 1
+    finally:
+        native_comm.set_loopback(False)
