@@ -63,6 +63,16 @@ bin/grayhipd: $(CSRC)/cli/main_server.cpp $(CLI_COMMON) $(CLI_CORE) $(CSRC)/cli/
 oracle:
 	$(MAKE) -C oracle all
 
+# developer build with the measurement probes (no-arithmetic skeletons, policy variants, handshake timestamps): never shipped,
+# selected with GRAYHIP_LIB=build_probes/libgrayhip_probes.so
+PROBE_OBJS := $(patsubst $(CSRC)/%.hip,build_probes/%.o,$(HIP_SRCS))
+build_probes/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p build_probes
+	$(HIPCC) $(HIPFLAGS) -DGH_ENABLE_PROBES -DGH_HALO_TRACE -c $< -o $@
+probes: build_probes/libgrayhip_probes.so
+build_probes/libgrayhip_probes.so: $(PROBE_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(PROBE_OBJS) -ldl -o $@
+
 # device assembly of the LDS-DMA kernels with the library's own flags (tests/test_isa_vmcnt.py analyses it)
 isa: build_isa/sobel.s build_isa/fused.s build_isa/conv3x3.s
 build_isa/%.s: $(CSRC)/%.hip $(HIP_HDRS)
@@ -74,7 +84,7 @@ clean:
 	rm -f $(HIP_OBJS) $(LIB) bin/grayscale bin/grayscale_sobel bin/grayhipd
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean isa
+.PHONY: all lib cli oracle clean isa probes
 
 # developer micro-benchmark (kernel variants; not shipped)
 ubench: bin/ubench

@@ -189,10 +189,16 @@ GH_API int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size
 GH_API int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev, gh_stream_t stream);
 /* number of halo-row ncclGroups this communicator has issued so far (diagnostic: one per sharded step, one per batch of prefetched frames) */
 GH_API unsigned long long gh_comm_exchange_count(gh_comm_t comm);
-/* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default: the one-row
- * exchange is enqueued on `stream`, then ONE launch covers the shard.  GH_SHARD_STEP_SERIAL=0: the exchange runs on the
- * communicator's side stream while the interior rows run on `stream`; the first and last row follow once the halo has
- * landed (pays two event hand-overs and two extra launches: slower for every shard size measured, comm.hip).
+/* Halo-flag waits that gave up (see gh_sharded_*_step_dev): 0 in every healthy run.  Non-zero means an exchange took longer than
+ * GH_HALO_WAIT_MS (default 10000) beside a launch whose edge bands were waiting for it; that step's edge rows are invalid and every
+ * later sharded step on this communicator fails. */
+GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
+/* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default (GH_SHARD_STEP_FORM=2, shards
+ * that run an LDS-DMA ring kernel: 1024 columns and more): the one-row exchange runs on the communicator's side stream BESIDE one launch
+ * over the whole shard on `stream`; only the workgroups of the first / last band wait -- inside the kernel -- for a flag set behind the
+ * ncclRecv, so the step costs max(kernel, exchange + one band) and the caller's stream sees one launch and no event.  Other shards, and
+ * GH_SHARD_STEP_FORM=1: the exchange on `stream`, then one launch (serial).  GH_SHARD_STEP_FORM=0: exchange on the side stream || interior
+ * rows, then the first and last row behind an event (two event hand-overs and two extra launches: the slowest form measured, comm.hip).
  * Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
  *   fused: buf = interleaved RGB8/RGBA8 rows, the halo is one RGB row (the luma plane never exists in HBM)
  *   sobel: buf = luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */

@@ -103,7 +103,34 @@ struct Comm {
     bool pf_waited[kPrefetch] = {};
     int pf_next = 0, pf_next_entry = 0;
     unsigned long long exchanges = 0;    // ncclGroups issued for halo rows (gh_comm_exchange_count: tests and bench.py read it)
+    // halo-flag form of the sharded step (gh_common.h): flag_dev[0] = flag the edge bands poll, flag_dev[32] = started (a cache
+    // line of its own), timeouts = host-mapped dword
+    uint32_t *flag_dev = nullptr;
+    uint32_t *started_sig = nullptr;     // `started` in signal memory (hipMallocSignalMemory) where the runtime has it: hipStreamWaitValue32 can poll it
+    uint32_t *timeouts_host = nullptr, *timeouts_dev = nullptr;
+    uint32_t epoch = 0;
 };
+
+__global__ void k_set_halo_flag(uint32_t *flag, uint32_t epoch)
+{
+    GH_HALO_TRACE_AT(flag, 2);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// in front of the exchange on the side stream: until the shard kernel of this step has begun on the caller's stream (gh_common.h)
+__global__ void k_wait_started(const uint32_t *started, uint32_t epoch, unsigned long long ticks, uint32_t *timeouts, const uint32_t *flag)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(started, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - epoch) >= 0) { GH_HALO_TRACE_AT(flag, 1); return; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
 
 }  // namespace
 
@@ -145,6 +172,19 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
         GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
         for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
+        GH_HIP_TRY(hipMalloc((void **)&c->flag_dev, 256));
+        GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
+        int can_wait = 0;
+        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, 0) == hipSuccess && can_wait &&
+            hipExtMallocWithFlags((void **)&c->started_sig, 8, hipMallocSignalMemory) == hipSuccess) {
+            if (hipMemset(c->started_sig, 0, 8) != hipSuccess) { (void)hipFree(c->started_sig); c->started_sig = nullptr; }
+        } else {
+            c->started_sig = nullptr;
+        }
+        (void)hipGetLastError();
+        GH_HIP_TRY(hipHostMalloc((void **)&c->timeouts_host, 64, hipHostMallocMapped));
+        memset(c->timeouts_host, 0, 64);
+        GH_HIP_TRY(hipHostGetDevicePointer((void **)&c->timeouts_dev, c->timeouts_host, 0));
         return GH_OK;
     }();
     if (rc != GH_OK) {
@@ -176,6 +216,9 @@ int gh_comm_destroy(gh_comm_t comm)
     for (int i = 0; i < Comm::kPrefetch; ++i)
         if (c->pf_landed[i]) (void)hipEventDestroy(c->pf_landed[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->flag_dev) (void)hipFree(c->flag_dev);
+    if (c->started_sig) (void)hipFree(c->started_sig);
+    if (c->timeouts_host) (void)hipHostFree(c->timeouts_host);
     delete c;
     return GH_OK;
 }
@@ -209,6 +252,25 @@ int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void 
 
 unsigned long long gh_comm_exchange_count(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->exchanges : 0; }
 
+#ifdef GH_HALO_TRACE
+// trace builds only (make probes): the handshake's 100 MHz timestamps of the LAST step (synchronises the device)
+extern "C" __attribute__((visibility("default"))) int gh_comm_halo_trace(gh_comm_t comm, unsigned long long out[8])
+{
+    GH_REQUIRE(comm && out, "null pointer");
+    GH_HIP_TRY(hipDeviceSynchronize());
+    GH_HIP_TRY(hipMemcpy(out, static_cast<Comm *>(comm)->flag_dev + 16, 64, hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+#endif
+
+// halo-flag waits that gave up (gh_common.h): 0 unless an exchange took longer than GH_HALO_WAIT_MS beside a launch that was waiting for it
+unsigned int gh_comm_halo_timeouts(gh_comm_t comm)
+{
+    if (!comm) return 0;
+    const Comm *c = static_cast<const Comm *>(comm);
+    return c->timeouts_host ? __atomic_load_n(c->timeouts_host, __ATOMIC_ACQUIRE) : 0;
+}
+
 int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream)
 {
     GH_REQUIRE(comm && buf_dev, "null pointer");
@@ -239,31 +301,73 @@ int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev, gh_str
 // buf: (rows + 2) rows of `row_bytes`; rows 1..rows are the shard, rows 0 / rows+1 receive the neighbours' edge rows.
 // Two forms: serial (exchange, then one launch) and overlapped (exchange on the side stream || interior rows on the caller's
 // stream -> first and last row once the halo has landed).
-template <typename Launch>
-static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */)
+template <typename Launch, typename LaunchWait>
+static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */,
+                        LaunchWait launch_wait /* (top_border, bot_border, const GhHaloWait &): the whole shard, edge bands wait for the flag */)
 {
     int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
     if (c->loopback) up = down = c->rank;      // a middle shard whose neighbours are itself: halo = its own edge rows
     if (up < 0 && down < 0) return launch(0, rows, 1, 1);
-    // Serial form (default; GH_SHARD_STEP_SERIAL=0 selects the overlapped form below): the exchange is enqueued on the caller's
-    // stream in front of ONE launch over the whole shard -- no side stream, no events, no one-row launches.  The exchange is then
-    // not hidden, but it moves one row (~11 us in the loopback rehearsal), while the overlapped form pays two cross-queue event
-    // hand-overs and two extra launches: 41 vs 58 us per step for the 2048-row shard of an 8-GPU split, 61 vs 65 us at 4096 rows,
-    // 110 vs 116 us at 8192 rows (tools/r2_call_o.sh; the pipelined form, which prefetches halos two frames ahead: 38 us).
-    if (GH_TUNE_INT("GH_SHARD_STEP_SERIAL", 1)) {
-        if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
-                                          row_bytes, s))
-            return rc;
+    if (gh_comm_halo_timeouts(c))
+        return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
+                            gh_comm_halo_timeouts(c));
+    uint8_t *send_up = buf + row_bytes, *recv_up = buf, *send_down = buf + (size_t)rows * row_bytes, *recv_down = buf + (size_t)(rows + 1) * row_bytes;
+    // Three forms (GH_SHARD_STEP_FORM; loopback rehearsal, 16384-wide shards of 2048 / 4096 / 8192 rows, us per step):
+    //  2 halo flag (default where the shard runs an LDS-DMA ring kernel): the exchange on the side stream BESIDE one launch over the whole
+    //    shard; only the first / last band's workgroups wait -- inside the kernel -- for a flag that a one-wave kernel behind the ncclRecv
+    //    sets.  No event on the caller's stream, no extra launches: the step costs max(kernel, exchange + one band).
+    //  1 serial: the exchange on the caller's stream in front of ONE launch -- no side stream, no events; the exchange (one row, ~11 us)
+    //    is not hidden: 41 / 61 / 110 us (round 2's default).
+    //  0 overlapped with events: exchange on the side stream || interior rows, then two one-row launches behind an event -- pays two
+    //    cross-queue event hand-overs and two extra launches: 58 / 65 / 116 us.
+    int form = GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
+    if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
+        GhHaloWait probe{};
+        probe.pad = 1;
+        if (launch_wait(up < 0, down < 0, probe) != GH_OK) form = 1;
+    }
+    if (form == 1) {
+        if (int rc = gh_halo_exchange_dev(c, up, send_up, recv_up, down, send_down, recv_down, row_bytes, s)) return rc;
         return launch(0, rows, up < 0, down < 0);
+    }
+    if (form == 2) {
+        // No event in either direction: the side stream polls `started` (stored by the shard kernel's first workgroup: everything
+        // enqueued on s before this step has completed by then -- the rows to send are in place, the previous step has read its halo
+        // rows), exchanges, and sets `flag`, which the shard kernel's edge bands poll.
+        // GH_HALO_MEMOPS (bit 1: the wait, bit 0: the flag write) hands the two side-stream operations to the command processor
+        // (hipStreamWaitValue32 on signal memory / hipStreamWriteValue32) instead of one-wave kernels.  Measured (tools/r3_shard_memops.sh,
+        // 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- hence 2.
+        const int memops = GH_TUNE_INT("GH_HALO_MEMOPS", 2);
+        const bool sig_wait = (memops & 2) && c->started_sig;
+        GhHaloWait hw{};
+        hw.flag = c->flag_dev;
+        hw.started = sig_wait ? c->started_sig : c->flag_dev + 32;
+        hw.timeouts = c->timeouts_dev;
+        hw.epoch = ++c->epoch;
+        hw.ticks = (unsigned long long)GH_TUNE_INT("GH_HALO_WAIT_MS", 10000) * 100000ull;       // 100 MHz constant clock
+        if (sig_wait) {
+            GH_HIP_TRY(hipStreamWaitValue32(c->side, c->started_sig, hw.epoch, hipStreamWaitValueGte, 0xffffffffu));
+        } else {
+            k_wait_started<<<1, 64, 0, c->side>>>(hw.started, hw.epoch, hw.ticks, hw.timeouts, c->flag_dev);
+            GH_LAUNCH_CHECK();
+        }
+        if (int rc = gh_halo_exchange_dev(c, up, send_up, recv_up, down, send_down, recv_down, row_bytes, c->side)) return rc;
+        if (memops & 1) {
+            GH_HIP_TRY(hipStreamWriteValue32(c->side, c->flag_dev, hw.epoch, 0));
+        } else {
+            k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, hw.epoch);
+            GH_LAUNCH_CHECK();
+        }
+        // Later work on s is ordered behind this launch, which cannot finish before the flag is set, i.e. before the exchange has
+        // completed: the caller may overwrite the shard's rows right after the step, as with the other forms.
+        return launch_wait(up < 0, down < 0, hw);
     }
     // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
     GH_HIP_TRY(hipEventRecord(c->ready, s));
     GH_HIP_TRY(hipStreamWaitEvent(c->side, c->ready, 0));
-    if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes,
-                                      row_bytes, c->side))
-        return rc;
+    if (int rc = gh_halo_exchange_dev(c, up, send_up, recv_up, down, send_down, recv_down, row_bytes, c->side)) return rc;
     GH_HIP_TRY(hipEventRecord(c->landed, c->side));
-    if (rows >= 3) {
+    if (form == 0 && rows >= 3) {
         if (int rc = launch(1, rows - 2, 0, 0)) return rc;                       // interior: local rows only
         GH_HIP_TRY(hipStreamWaitEvent(s, c->landed, 0));
         if (int rc = launch(0, 1, up < 0, 0)) return rc;
@@ -434,6 +538,8 @@ int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, i
     const size_t rb = (size_t)width * channels;
     return sharded_step(c, rgb_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
         return gh_gray_sobel_fused_rows_dev(rgb_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, channels, mode, tb, bb, stream);
+    }, [&](int tb, int bb, const GhHaloWait &hw) {
+        return gh_fused_rows_halo_wait(rgb_buf + rb, edge, width, rows, channels, mode, tb, bb, stream, &hw);
     });
 }
 
@@ -447,6 +553,8 @@ int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, 
     const size_t rb = (size_t)width;
     return sharded_step(c, luma_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
         return gh_sobel_u8_rows_dev(luma_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, tb, bb, stream);
+    }, [&](int tb, int bb, const GhHaloWait &hw) {
+        return gh_sobel_rows_halo_wait(luma_buf + rb, edge, width, rows, tb, bb, stream, &hw);
     });
 }
 
@@ -464,7 +572,7 @@ int gh_sharded_conv3x3_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *dst, 
     const size_t rb = (size_t)width * 3;
     return sharded_step(c, rgb_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
         return gh_conv3x3_rgb8_rows_dev(rgb_buf + (size_t)(first + 1) * rb, dst + (size_t)first * rb, width, n, kernel, norm, tb, bb, stream);
-    });
+    }, [&](int, int, const GhHaloWait &) { return GH_NO_FLAG_FORM; });       // (the convolution kernels carry no flag wait: serial form)
 }
 
 // `passes` x (gray -> extract -> Sobel -> replicate) on a row shard (monolithic/src/main_with_sobel.c:49-76 on a sharded frame, SURVEY.md

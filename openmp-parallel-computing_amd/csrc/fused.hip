@@ -283,7 +283,7 @@ __device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
 template <int MODE, int D, int SP, int CH = 3, int UNAL = 0, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK)
 void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w, int rows, int groups_x, BandPlan plan, int zero_top,
-                 int zero_bot)
+                 int zero_bot, GhHaloWait hw)
 {
     using namespace stream_core;
     constexpr int PRE = UNAL ? 16 : 0;                            // UNAL: room in front of the lane grid (pieces land up to 16 bytes early)
@@ -316,7 +316,13 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
     if (REG && y0 + R > rows) y0 = rows - R;                     // regular bands: the last band is shifted up to end at the frame edge (see k_sobel_dma)
     const int nrows = min(R, rows - y0) + 2;                     // input rows of this band (clipped to the frame) incl. halo
     const int nch = (nrows + CHK - 1) / CHK;
-    const bool up = band_walks_up(plan, gy_i);
+    // Sharded step, halo-flag form (gh_common.h): a band that reads a halo row waits -- right before it requests that row -- until the
+    // exchange beside this launch has landed.  The shard's FIRST band walks upward (the rolling window is symmetric under the reversal),
+    // so that its halo row, like the last band's, is the last row it needs: by then the exchange has normally completed and the wait
+    // costs nothing (waiting at the start of the band would delay the whole band, and with every workgroup resident at once a band
+    // lasts as long as the launch).
+    const bool up = band_walks_up(plan, gy_i) || (hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows);
+    if (hw.flag) gh_halo_started(hw);
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw * CH + (uint32_t)lane * 16u;            // byte offset of this lane's piece in a row
     // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its bytes 1..3),
@@ -344,6 +350,10 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         return uniform_ptr(rgb + ((ptrdiff_t)yy * w + xw) * CH);
     };
     auto issue_row = [&](int i, int slot) {
+        if (hw.flag) {                                           // (wave-uniform) halo row of a shard: has the exchange landed?
+            const int raw = up ? y0 + nrows - 2 - i : y0 - 1 + i;
+            if ((raw < 0 && !zero_top) || (raw >= rows && !zero_bot)) gh_halo_wait(hw);
+        }
         const uint32_t dst = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         // always exactly NLD vector-memory instructions, one statement
         if (UNAL) {
@@ -485,17 +495,18 @@ __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__res
 // launch arguments of k_fused_dma, and the channel / mode dispatch
 struct DmaLaunch {
     const uint8_t *rgb; uint8_t *edge; int width, rows, groups_x; BandPlan plan; int zt, zb, channels, mode; unsigned grid; size_t pad; hipStream_t s;
+    GhHaloWait hw;
 };
 template <int D, int SP, int UNAL = 0, int REG = 0>
 void launch_fused_dma(const DmaLaunch &L)
 {
     const unsigned b = stream_core::BLOCK;
     if (L.channels == 4) {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb, L.hw);
+        else k_fused_dma<GH_MODE_IEEE, D, SP % 10, 4, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb, L.hw);
     } else {
-        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
-        else k_fused_dma<GH_MODE_IEEE, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb);
+        if (L.mode == GH_MODE_FMA) k_fused_dma<GH_MODE_FMA, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb, L.hw);
+        else k_fused_dma<GH_MODE_IEEE, D, SP, 3, UNAL, REG><<<L.grid, b, L.pad, L.s>>>(L.rgb, L.edge, L.width, L.rows, L.groups_x, L.plan, L.zt, L.zb, L.hw);
     }
 }
 
@@ -503,6 +514,14 @@ void launch_fused_dma(const DmaLaunch &L)
 
 extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode,
                                             int top_is_border, int bottom_is_border, gh_stream_t stream)
+{
+    return gh_fused_rows_halo_wait(rgb, edge, width, rows, channels, mode, top_is_border, bottom_is_border, stream, nullptr);
+}
+
+// hw != nullptr: the halo-flag form of the sharded step (gh_common.h) -- only the LDS-DMA ring kernel carries the wait; a frame that
+// would run another form is refused with GH_NO_FLAG_FORM before anything is launched.
+int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode, int top_is_border,
+                            int bottom_is_border, gh_stream_t stream, const GhHaloWait *hw)
 {
     GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
     GH_REQUIRE(channels == 3 || channels == 4, "fused kernel takes RGB8 or RGBA8");
@@ -529,13 +548,15 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
     // global side, every strip is full); GH_FUSED_DMA_UNALIGNED=0 sends unaligned frames to the register-staged strips + tail.
     const int dma_knob = GH_TUNE_INT("GH_FUSED_DMA", -1);      // ring depth D (0 = register-staged kernel, -1 = auto)
     const bool dma_ok = dma_knob != 0 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 1));
+    static const bool use_tile_env = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
+    if (hw && (!dma_ok || (use_tile_env && aligned))) return GH_NO_FLAG_FORM;
+    if (hw && hw->pad) return GH_OK;             // probe: the LDS-DMA ring kernel will run
     if (!aligned && !dma_ok && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
         gh_note_kernel("k_fused_px_cols");
         launch_px_cols(0);
         GH_LAUNCH_CHECK();
         return GH_OK;
     }
-    static const bool use_tile_env = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
     const bool use_tile = use_tile_env && aligned;
     if (!use_tile) {
         const int variant = GH_TUNE_INT("GH_FUSED_VARIANT", 0);   // tuning knob
@@ -600,7 +621,7 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
             }
             if (pad_kb < 0) pad_kb = 0;
             const size_t pad = (size_t)pad_kb * 1024;
-            const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s};
+            const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s, hw ? *hw : GhHaloWait{}};
             // frames with unaligned rows: GH_FUSED_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_fused_dma, UNAL), 1 = pieces from
             // the strip's own unaligned address, 0 = register-staged strips + column tail
             const int unal = aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 2) < 2 || dma == 4 ? 0

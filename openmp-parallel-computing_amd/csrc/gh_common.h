@@ -37,6 +37,32 @@ int gh_ensure_init();   // lazy gh_init(GRAYHIP_DEVICE or 0)
 // the kernels DESIGN.md says they run, instead of silently falling to a slower form)
 void gh_note_kernel(const char *name);
 
+// ---- halo-flag form of the sharded steps (comm.hip) ---------------------------------------------------------------------------
+// The one-row exchange of a shard runs on the communicator's side stream WHILE one launch covers the whole shard on the caller's
+// stream, and the two sides meet through two dwords in device memory instead of stream events (a cross-queue event hand-over costs
+// ~20 us on this runtime; a polled dword ~2):
+//   started  the shard kernel's first workgroup stores the step's epoch there when it begins -- by stream order every earlier piece of
+//            work on the caller's stream has completed then (the rows to send are in place, the previous step has read its halo rows);
+//            the side stream polls it in front of the exchange;
+//   flag     set to the epoch behind the ncclRecv; only the workgroups of the first / last band, whose rows depend on a halo row, poll
+//            it before they issue their first load; every other workgroup starts at once.
+// A wait that outlasts `ticks` of the 100 MHz constant clock gives up, counts itself in *timeouts (host-mapped memory: the next sharded
+// call sees it without a synchronisation and fails) and lets the wave finish -- every wave reaches its exit whatever happens to the
+// exchange.  flag == nullptr: no wait (every other caller of the kernels).
+struct GhHaloWait {
+    const uint32_t *flag;
+    uint32_t *started;
+    uint32_t *timeouts;
+    uint32_t epoch;
+    uint32_t pad;                 // host side: 1 = "would this frame run a kernel form that carries the wait?" (GH_OK / GH_NO_FLAG_FORM, nothing launched)
+    unsigned long long ticks;
+};
+constexpr int GH_NO_FLAG_FORM = -100;      // internal: this frame shape runs a kernel form without the flag wait (narrow frames, per-pixel kernels)
+int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode, int top_is_border,
+                            int bottom_is_border, gh_stream_t stream, const GhHaloWait *hw);
+int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border, gh_stream_t stream,
+                            const GhHaloWait *hw);
+
 static inline bool gh_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // MI355X: 256 CUs in 8 XCDs
@@ -70,6 +96,38 @@ __device__ __forceinline__ uint32_t gh_luma(uint32_t r, uint32_t g, uint32_t b)
         y = s + pb;
     }
     return (uint32_t)y;
+}
+
+// the wait itself (wave-uniform: every lane polls the same dword; acquire at system scope, so that the halo rows -- written by the
+// RCCL kernel of this device or, over xGMI, by the neighbour's -- are re-fetched behind it instead of served from this XCD's L2)
+// GH_HALO_TRACE builds (make probes): 100 MHz timestamps of the handshake in the 8 u64 behind the flag's cache line (flag + 16 dwords):
+// [0] shard kernel's first workgroup began, [1] side stream saw `started`, [2] flag set, [3] / [4] an edge band began / ended its wait
+#ifdef GH_HALO_TRACE
+#define GH_HALO_TRACE_AT(flagp, k) \
+    do { if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(flagp) + 16)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GH_HALO_TRACE_AT(flagp, k) do { } while (0)
+#endif
+__device__ __forceinline__ void gh_halo_started(const GhHaloWait &hw)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(hw.started, hw.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        GH_HALO_TRACE_AT(hw.flag, 0);
+    }
+}
+__device__ __forceinline__ void gh_halo_wait(const GhHaloWait &hw)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    GH_HALO_TRACE_AT(hw.flag, 3);
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(hw.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - hw.epoch) >= 0) { GH_HALO_TRACE_AT(hw.flag, 4); return; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > hw.ticks) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(hw.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
 }
 
 // byte k (0..3) of a dword, as an unsigned int (lowers to v_cvt_f32_ubyteK / v_bfe_u32)

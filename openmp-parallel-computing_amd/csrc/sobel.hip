@@ -133,7 +133,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // its two neighbours are re-aligned in registers, six v_alignbyte_b32 with the row's (wave-uniform) s.
 template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0, int REG = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
-                                                                 int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
+                                                                 int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
 {
     using namespace stream_core;
     constexpr int PRE = UNAL ? 16 : 0;                           // UNAL: 16 bytes in front of the lane grid (the piece may land up to 16 early)
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
                                                 // full, the rows it shares with the band above are computed and stored twice with identical bytes
     const int nrows = min(R, rows - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
-    const bool up = band_walks_up(plan, gy_i);
+    // sharded step, halo-flag form (gh_common.h; see k_fused_dma): the shard's first band walks upward, so that a band's halo row is the
+    // LAST row it requests, and the wait for the exchange sits right in front of that request
+    const bool up = band_walks_up(plan, gy_i) || (hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows);
+    if (hw.flag) gh_halo_started(hw);
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
@@ -194,6 +197,10 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         return uniform_ptr(src + (ptrdiff_t)yy * w + xw);
     };
     auto issue_row = [&](int i, int slot) {
+        if (hw.flag) {                                           // (wave-uniform) halo row of a shard: has the exchange landed?
+            const int raw = up ? y0 + nrows - 2 - i : y0 - 1 + i;
+            if ((raw < 0 && !zero_top) || (raw >= rows && !zero_bot)) gh_halo_wait(hw);
+        }
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         if (UNAL) {
             const uint8_t *A = strip_row(i);
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // dword-shifted (1), plus the byte re-alignment of both strips (2) -- exactly k_sobel_dma's scheme on a 2 KiB row.
 template <int D, int LB = 1, int REG = 0, int UNAL = 0>
 __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
-                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot)
+                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
 {
     using namespace stream_core;
     constexpr int SW = 2 * STRIP_PX;
@@ -335,6 +342,9 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     if (REG && y0 + R > rows) y0 = rows - R;    // regular bands: the last band is shifted up to end at the frame edge (see k_sobel_dma)
     const int nrows = min(R, rows - y0) + 2;
     const int nch = (nrows + CHK - 1) / CHK;
+    // sharded step, halo-flag form (gh_common.h; see k_fused_dma): first band upward, the wait in front of the halo row's request
+    const bool up = hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows;
+    if (hw.flag) gh_halo_started(hw);
     __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
@@ -348,10 +358,14 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
 
     const bool has_right = xw + SW < w;
     auto strip_row = [&](int i) {                                // first byte of the strip pair in band row i (wave-uniform)
-        const int yy = clamp_row(y0 - 1 + i, rows, zero_top, zero_bot);
+        const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
         return uniform_ptr(src + (ptrdiff_t)yy * w + xw);
     };
     auto issue_row = [&](int i, int slot) {                      // always exactly 3 vector-memory instructions
+        if (hw.flag) {                                           // (wave-uniform) halo row of a shard: has the exchange landed?
+            const int raw = up ? y0 + nrows - 2 - i : y0 - 1 + i;
+            if ((raw < 0 && !zero_top) || (raw >= rows && !zero_bot)) gh_halo_wait(hw);
+        }
         const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
         if (UNAL) {                                              // see k_sobel_dma: a', the tail blocks, the landing offset
             const uint8_t *A = strip_row(i);
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         if (UNAL) hh = make_uint2(*reinterpret_cast<const uint32_t *>(slotp + PRE - 4), *reinterpret_cast<const uint32_t *>(slotp + PRE + SW));
         else hh = *reinterpret_cast<const uint2 *>(slotp + SW);
         const uint32_t sh = UNAL == 2 ? (uint32_t)(uintptr_t)strip_row(i) & 3u : 0u;     // the pair starts at byte sh of the lane grid
-        const int y = y0 + i - 2;
+        const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
         const bool zero_row = (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
         auto strip = [&](auto sub_c, StateF2 &st, uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
             constexpr int SUB = decltype(sub_c)::value;
@@ -777,6 +791,16 @@ extern "C" {
 int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border,
                          gh_stream_t stream)
 {
+    return gh_sobel_rows_halo_wait(src, dst, width, rows, top_is_border, bottom_is_border, stream, nullptr);
+}
+
+}  // extern "C"
+
+// hw != nullptr: the halo-flag form of the sharded step (gh_common.h) -- only the LDS-DMA ring kernels carry the wait; a frame that would
+// run another form (or the two-launch split of k_sobel_dma2) is refused with GH_NO_FLAG_FORM before anything is launched.
+int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border, gh_stream_t stream,
+                            const GhHaloWait *hw)
+{
     GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
     if (width == 0 || rows == 0) return GH_OK;
     GH_REQUIRE(src && dst, "null pointer");
@@ -798,6 +822,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     // to end at the frame edge), so a row pitch that is not a multiple of 16 changes nothing but the address arithmetic --
     // no per-pixel column tail.  GH_SOBEL_DMA_UNALIGNED=0 sends such frames back to the register-staged strips + tail.
     const bool use_dma = !use_tile && dma && core == 1 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 1));
+    if (hw && (!use_dma || dma != 3)) return GH_NO_FLAG_FORM;      // (dma != 3: the probe forms)
+    const GhHaloWait hwv = hw ? *hw : GhHaloWait{};
     const bool strips = !use_tile && ws >= 16 &&
                         (aligned || use_dma || (GH_TUNE_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_TUNE_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
     if (strips) {
@@ -864,6 +890,7 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
                 const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, GH_NUM_CU);
                 if (overflow2 && (long long)width * rows >= (1ll << 28)) {
+                    if (hw) return GH_NO_FLAG_FORM;
                     const int main_rows = rows - rows % R2;
                     if (int rc = gh_sobel_u8_rows_dev(src, dst, width, main_rows, top_is_border, 0, stream)) return rc;
                     return gh_sobel_u8_rows_dev(src + (size_t)main_rows * width, dst + (size_t)main_rows * width, width, rows - main_rows, 0, bottom_is_border, stream);
@@ -872,28 +899,30 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 // (frames with unaligned rows only on request: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
                 //  one strip per wave -- the gain belongs to row pitches that keep the row streams in step; 16368 wide: 0.1079 vs 0.1086)
                 if (regular && wanted) {
+                    if (hw && hw->pad) return GH_OK;      // probe: k_sobel_dma2 will run
                     stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
                     p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2);
                     const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
 #ifdef GH_ENABLE_PROBES
                     const int nsd = GH_TUNE_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: DESIGN.md)
-                    if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                    else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                    else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                    else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);     // regular-band form, other depths
-                    else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                    if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                    else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                    else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                    else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);     // regular-band form, other depths
+                    else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
                     else
 #endif
                     {
                         gh_note_kernel(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
-                        if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                        else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
-                        else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb);
+                        if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                        else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                        else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
                     }
                     GH_LAUNCH_CHECK();
                     return GH_OK;
                 }
             }
+            if (hw && hw->pad) return GH_OK;              // probe: k_sobel_dma will run
             const int unal = aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? 0 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
             // Regular-band (branch-free) form of the one-strip kernel, 128-134 VGPRs: every band has R + 2 input rows in whole chunks of 6.
             // With 16-row bands -- the mid-size and small frames, where a wave's row step is latency-bound and the generic form's scalar
@@ -904,19 +933,19 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                               !stream_core::shifted_band_overflows(groups_x, rows, R, 3, GH_NUM_CU);
             gh_note_kernel(reg1 ? (unal ? "k_sobel_dma regular R=16 unaligned" : "k_sobel_dma regular R=16") : (unal ? "k_sobel_dma unaligned" : "k_sobel_dma"));
             if (reg1) {
-                if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-                else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-                else k_sobel_dma<3, 0, 2, 1, 2, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+                else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+                else k_sobel_dma<3, 0, 2, 1, 2, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
             }
             else if (unal && sp == 0) {
-                if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-                else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+                else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
             } else if (unal) {
-                if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-                else k_sobel_dma<3, 0, 2, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+                if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+                else k_sobel_dma<3, 0, 2, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
             }
-            else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+            else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
 #ifdef GH_ENABLE_PROBES
             else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW
                 const int rw = dma - 100, skew = GH_TUNE_INT("GH_SOBEL_SKEW", 3);
@@ -960,18 +989,18 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
                 else if (dma == 31203) k_wide_strip_probe<12, 3, 1, 3><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
                 else GH_REQUIRE(false, "3:1 wide-strip probe: unknown size / depth");
             }
-            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no sqrt (wrong results)
-            else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);        // timing probe: no arithmetic (wrong results)
-            else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);   // probe: row-synchronous workgroup
-            else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);   // the same without arithmetic
-            else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);  // probe: default-policy DMA loads
-            else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no sqrt (wrong results)
+            else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no arithmetic (wrong results)
+            else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // probe: row-synchronous workgroup
+            else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // the same without arithmetic
+            else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);  // probe: default-policy DMA loads
+            else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
 #endif
-            else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 3) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
-            else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb);
+            else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+            else if (dma == 3) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+            else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+            else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+            else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
             GH_LAUNCH_CHECK();
             return GH_OK;
         }
@@ -1009,6 +1038,8 @@ int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, 
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
+
+extern "C" {
 
 int gh_sobel_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, gh_stream_t stream)
 {

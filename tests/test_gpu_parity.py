@@ -520,14 +520,15 @@ def test_native_comm_self_exchange(pkg, native_comm, torch_mod):
     assert sums.cpu().tolist() == [1, 2, 3]
 
 
-@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130)])
-@pytest.mark.parametrize("serial", ["1", "0"])
-def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, serial, monkeypatch):
-    """The C++ sharded step -- serial form (exchange on the caller's stream, then one launch over the shard: the default) and
-    overlapped form (exchange on the side stream || interior rows, then first / last row) -- as a middle shard whose
-    neighbours are itself: the halo rows must become copies of the shard's own edge rows, i.e. the result equals the
-    oracle on the frame padded by replicating its first and last row."""
-    monkeypatch.setenv("GH_SHARD_STEP_SERIAL", serial)
+@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130), (16384, 2048), (1031, 70), (8192, 128), (512, 20)])
+@pytest.mark.parametrize("form", ["2", "1", "0"])
+def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, monkeypatch):
+    """The C++ sharded step in its three forms -- 2 halo flag (default: exchange on the side stream beside ONE launch whose first /
+    last band wait for a flag inside the kernel), 1 serial (exchange on the caller's stream, then one launch), 0 overlapped with
+    events (exchange || interior rows, then first / last row) -- as a middle shard whose neighbours are itself: the halo rows must
+    become copies of the shard's own edge rows, i.e. the result equals the oracle on the frame padded by replicating its first and
+    last row.  The halo rows start out poisoned and the steps are repeated, so a band that did not wait for its halo shows."""
+    monkeypatch.setenv("GH_SHARD_STEP_FORM", form)
     t = torch_mod
     img = oracle.frame_rand(w, h, 3, seed=w * 7 + h)
     padded = np.concatenate([img[:1], img, img[-1:]], axis=0)
@@ -539,23 +540,35 @@ def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h
         geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
         backend = pkg.sharding.HipBackend(0)
         # fused: RGB halo rows
-        buf = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+        buf = t.full((h + 2, w, 3), 0xA5, dtype=t.uint8, device="cuda")
         buf[1:h + 1] = dev(t, img)
         edge = t.full((h, w), 7, dtype=t.uint8, device="cuda")
         step = native_comm.bind_fused_step(buf, edge, h, 0)
+        step()                          # the very first step: halo rows still poisoned when the launch is enqueued
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), want)
         for _ in range(3):              # repeated steps: the exchange of step k+1 must wait for step k's edge rows
+            buf[0] = 0x5A               # (enqueued on the same stream, in front of the step)
+            buf[h + 1] = 0x5A
             step()
         t.cuda.synchronize()
         assert np.array_equal(buf[0].cpu().numpy(), img[0]) and np.array_equal(buf[h + 1].cpu().numpy(), img[-1])
         assert np.array_equal(edge.cpu().numpy(), want)
+        assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
         # split: luma halo rows
-        luma = t.zeros((h + 2, w), dtype=t.uint8, device="cuda")
+        luma = t.full((h + 2, w), 0xA5, dtype=t.uint8, device="cuda")
         backend.gray_to_plane(dev(t, img), luma[1:h + 1])
         edge2 = t.full((h, w), 9, dtype=t.uint8, device="cuda")
         step2 = native_comm.bind_sobel_step(luma, edge2, h)
+        step2()
+        t.cuda.synchronize()
+        assert np.array_equal(edge2.cpu().numpy(), want)
+        luma[0] = 0x5A
+        luma[h + 1] = 0x5A
         step2(); step2()
         t.cuda.synchronize()
         assert np.array_equal(edge2.cpu().numpy(), want)
+        assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
         del geom
     finally:
         native_comm.set_loopback(False)

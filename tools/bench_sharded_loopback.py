@@ -31,7 +31,7 @@ for world in WORLDS:
         pstep(cnt[0]); cnt[0] += 1
     def piped3():
         pstep3(cnt[0]); cnt[0] += 1
-    for name, fn in (("native sharded step (exchange || interior, then edge rows)", step), ("native pipelined step, halo 1 frame ahead", piped),
+    for name, fn in (("native sharded step (GH_SHARD_STEP_FORM: 2 halo flag, 1 serial, 0 events)", step), ("native pipelined step, halo 1 frame ahead", piped),
                      ("native pipelined step, halo 2 frames ahead", piped3), ("native batched step, halos of 4 frames per exchange (ring of 8)", batched4),
                      ("native batched step, halos of 2 frames per exchange (ring of 8)", batched2), ("single launch, no exchange", whole)):
         if ONLY and ONLY not in name: continue
