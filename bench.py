@@ -20,13 +20,17 @@ the same kernel inside the gray -> Sobel pipeline, between two per-step event re
 N > 1: the frame is row-sharded, one process per GPU, and every step exchanges a one-row halo with each neighbour over
 RCCL: an RGB row for the fused pipeline, a luma row for the split one.  Three step forms are timed, each with the
 contract's bracket (barrier + synchronize on both sides, MAX over ranks):
-    pipelined     a stream of frames in a ring of eight buffers; the halo rows of the next four frames travel in ONE exchange while
-                  the current four run, one launch per step (`value`; --halo-batch 0: one exchange per frame, two frames ahead,
-                  as in round 1);
-    single_frame  ONE frame, strong-scaled (BASELINE configs[3] as written: the latency of one sharded frame): the one-row
-                  exchange, then one launch over the shard (libgrayhip's default; its overlapped form -- exchange || interior
-                  rows, then first and last row -- measured slower at every shard size, csrc/comm.hip);
-    end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory.
+    single_frame  ONE frame, strong-scaled -- BASELINE configs[3] as written, and therefore `value`: per step every rank exchanges
+                  its edge rows with its neighbours and filters its shard.  libgrayhip's default form runs the exchange on a side
+                  stream beside ONE launch over the shard whose first / last band wait, inside the kernel, for a flag set behind
+                  the ncclRecv (csrc/comm.hip; GH_SHARD_STEP_FORM=1: exchange, then launch);
+    end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory (SURVEY 8(d));
+    pipelined     a different experiment, reported beside it: a STREAM of frames in a ring of eight buffers, the halo rows of the
+                  next four frames travel in ONE exchange while the current four run, one launch per step (--halo-batch 0: one
+                  exchange per frame, two frames ahead).
+The line also says who issued the exchange (`exchange_fallback` true = torch.distributed P2P instead of libgrayhip's own RCCL
+communicator), fails (rc 4) when that communicator did not meet all N ranks, and carries a per-rank breakdown -- shard kernel alone,
+exchange alone, the whole step -- so that one run explains the shape of the scaling curve.
 Every kernel is the hand-written gfx950 code in libgrayhip.so, called through its C ABI; torch is only
 the allocator, the stream provider and the process group.
 
@@ -84,6 +88,8 @@ def parse_args():
                     help="N > 1, pipelined form: 1 (default) the halo rows of four future frames per exchange (gh_sharded_prefetch_halos_dev), "
                          "0 one exchange per frame, two frames ahead")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity checks")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step bracket of `value` is repeated this many times in all (the first one is `value`); min / median / max in `repeats`")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed run-in before the W warm-up steps: after ~2 ms of load the GPU's power management dips the clocks and "
                          "takes 30-60 ms to settle (tools/drift_start.py: launches 10-40 of a burst run 25-40 %% slower); "
@@ -151,27 +157,54 @@ def sha256_of(t) -> str:
 
 # ---- committed PMC evidence ---------------------------------------------------------------------------------------------
 
-def measured_traffic(kernel_name: str, px: int):
+def measured_traffic(kernel_name: str, px: int, live_ms: float | None = None, live_form: str = ""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/<LATEST>/pmc_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction), scaled to this launch's
-    pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself.  A summary whose
-    two passes averaged very different numbers of launches (an outlier filter gone wrong) is refused."""
+    pixel count.  A recorded measurement, not a live one: bench.py cannot run the profiler on itself -- so it is only reported
+    while THIS run looks like the run that was profiled: the device kernel the launch rules picked must be the profiled symbol and
+    its live, event-timed average duration must lie within 5 % of the profile's average for that symbol (rocprofv3 --stats of the
+    same command, kernel_stats.csv beside the counters).  A kernel change that doubled the traffic would change the duration (these
+    kernels are HBM-bound) or the symbol; then `traffic` is null and the reason is given instead.  A summary whose two passes
+    averaged very different numbers of launches (an outlier filter gone wrong) is refused too.
+    Returns (bytes or None, source or reason, cross-check dict)."""
     sym = {"gray_sobel_fused_rgb8": ("k_fused_dma", "k_fused_stream"), "gray_rgb8_to_plane": ("k_gray_rgb_to_plane_w",),
            "sobel3x3_u8": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream"), "sobel3x3_u8_after_gray": ("k_sobel_dma2", "k_sobel_dma", "k_sobel_stream")}
     try:
         latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
         f = os.path.join(ROOT, "profiles", latest, "pmc_hbm_traffic.json")
+        rel = os.path.relpath(f, ROOT)
         kernels = json.load(open(f)).get("kernels", {})
         for name in sym[kernel_name]:
             k = kernels.get(name)
             if k and "hbm_total_bytes" in k:
                 n = k.get("launches_averaged", [0, 0])
                 if min(n) < 1 or max(n) > 10 * min(n):
-                    return None, f"{os.path.relpath(f, ROOT)} refused: launches averaged {n}"
-                return int(k["hbm_total_bytes"] / (16384 * 16384) * px), os.path.relpath(f, ROOT)
+                    return None, f"{rel} refused: launches averaged {n}", None
+                cross = None
+                if live_ms is not None:
+                    if live_form and not (live_form.split()[0] == name):
+                        return None, f"{rel} not applicable: this run launched {live_form!r}, the profile holds {name}", None
+                    prof_ns = None
+                    try:
+                        import csv
+                        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", latest, "kernel_stats.csv"))):
+                            if f"::{name}<" in r["Name"] or f" {name}<" in r["Name"] or f"::{name}(" in r["Name"]:
+                                if prof_ns is None or int(r["Calls"]) > prof_ns[1]:
+                                    prof_ns = (float(r["AverageNs"]), int(r["Calls"]))
+                    except Exception:
+                        prof_ns = None
+                    if prof_ns is None:
+                        return None, f"{rel} not cross-checked: no kernel_stats.csv entry for {name}", None
+                    scale = px / (16384 * 16384)
+                    ratio = live_ms * 1e6 / (prof_ns[0] * scale)
+                    cross = {"live_avg_us": round(live_ms * 1e3, 2), "profiled_avg_us": round(prof_ns[0] * scale / 1e3, 2), "ratio": round(ratio, 4),
+                             "tolerance": 0.05, "profile": f"profiles/{latest}/kernel_stats.csv"}
+                    if abs(ratio - 1.0) > 0.05:
+                        return None, f"{rel} withheld: live launch duration is {ratio:.3f} x the profiled one (tolerance 5 %)", cross
+                return int(k["hbm_total_bytes"] / (16384 * 16384) * px), rel, cross
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 # ---- the reference's CPU path on this box's host cores ------------------------------------------------------------------
@@ -472,6 +505,19 @@ def main() -> int:
                 native.allreduce_sum_u64(one, stream.cuda_stream)
                 torch.cuda.synchronize()
                 rccl_ranks = int(one.item())
+            # the line must never quietly time torch P2P when libgrayhip's communicator was asked for: on real ranks that is a failure
+            if not rehearsal and (native is None or rccl_ranks != world):
+                msg = f"libgrayhip's RCCL communicator met {rccl_ranks} of {world} ranks" if native is not None else \
+                    f"libgrayhip's RCCL communicator could not be created ({exchange_note or 'on another rank'})"
+                print(f"bench.py: {msg}; refusing to time the torch.distributed fallback in its place (--exchange torch asks for it explicitly)",
+                      file=sys.stderr)
+                if rank == 0:
+                    os.write(json_fd, (json.dumps({"metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel", "value": None, "unit": "Mpixels/s",
+                                                   "n_gpus": world, "error": msg, "ranks": ranks_met, "rccl_ranks": rccl_ranks,
+                                                   "exchange_fallback": True}) + "\n").encode())
+                dist.barrier()
+                dist.destroy_process_group()
+                return 4
 
     # Synthetic frames, resident in HBM before the timed region: SURVEY.md 8(c) rand(seed), this rank's rows of it.
     # N = 1: one frame, rand(seed=1).  N > 1: a ring of eight frames, rand(seed = 1 .. 8) (a stream of frames, step k works
@@ -550,6 +596,11 @@ def main() -> int:
         run_in(first)
         elapsed, host_enqueue = timed(first, args.steps, ev1, rv1)
         step_ms_events = rv1[0].elapsed_time(rv1[1]) / args.steps
+        # the same bracket again (same K, no run-in between): box noise made visible -- `value` stays the FIRST bracket
+        rep_ms = [elapsed / args.steps * 1e3]
+        for _ in range(max(args.repeats, 1) - 1):
+            el_r, _ = timed(first, args.steps, None, None)
+            rep_ms.append(el_r / args.steps * 1e3)
         timed_kernels, region_of = {}, {}
 
         def note(events, is_fused, region, pair=None):
@@ -678,14 +729,18 @@ def main() -> int:
         first_kernels = {k: v for k, v in timed_kernels.items() if region_of[k] == "value"}
         dom = max(first_kernels, key=first_kernels.get)
         a = kern_table[dom]["GB/s"]
-        traffic, traffic_src = measured_traffic(dom, px_rank)
+        traffic, traffic_src, traffic_cross = measured_traffic(dom, px_rank, kern_table[dom]["ms"], kern_table[dom].get("device_kernel", ""))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_cross_check": traffic_cross,
                     "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"],
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "frac_of_copy_ceiling": round(a / copy_ceiling, 4) if copy_ceiling else None}
         out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
-                    "kernels": kern_table, "ms_per_step_events": round(step_ms_events, 4), "second_timed_region": other, "third_timed_region": sobel_alone,
+                    "kernels": kern_table, "ms_per_step_events": round(step_ms_events, 4),
+                    "repeats": {"ms_per_step": [round(v, 4) for v in rep_ms], "min": round(min(rep_ms), 4),
+                                "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4), "max": round(max(rep_ms), 4),
+                                "note": "the K-step bracket run again back to back; value / ms_per_step are the first entry"},
+                    "second_timed_region": other, "third_timed_region": sobel_alone,
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1)})
         parallelism = "single GPU"
@@ -782,8 +837,18 @@ def main() -> int:
                     "host_enqueue_us_per_step": round(host * 1e6 / k_steps, 1), "steps": k_steps}, el
 
         forms = {}
-        # (b) ONE frame, strong-scaled: the one-row exchange, then one launch over the shard
-        forms["single_frame"], _ = run_form(single_impl, args.steps, "single_frame")
+        xc0 = native.exchange_count() if native is not None else 0
+        # (a) ONE frame, strong-scaled (BASELINE configs[3]): every step = one halo exchange + the shard -- `value`
+        forms["single_frame"], elapsed = run_form(single_impl, args.steps, "single_frame")
+        value = W * H_total * args.steps / elapsed / 1e6
+        step_ms_events = forms["single_frame"]["ms_per_step_events_rank0"]
+        rep_ms = [elapsed / args.steps * 1e3]
+        fn_single = with_events(single_impl, "single_frame_repeats")
+        for _ in range(max(args.repeats, 1) - 1):
+            el_r, _ = timed(fn_single, args.steps, None, None)
+            rep_ms.append(el_r / args.steps * 1e3)
+        if native is not None:
+            forms["single_frame"]["exchanges_per_step"] = round((native.exchange_count() - xc0) / max(calls["single_frame"] + calls["single_frame_repeats"], 1), 3)
         # Sum of the edge plane over all ranks against the compiled reference's known answer (single-frame form, frame rand(seed=1))
         edge_sum_check = "skipped"
         if not args.no_check and not rehearsal_loopback:
@@ -797,7 +862,62 @@ def main() -> int:
                     f"MISMATCH ({int(tsum.item())} != {want})"
             else:
                 edge_sum_check = f"unpinned geometry (sum {int(tsum.item())})"
-        # (c) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
+
+        # Per-rank breakdown of the single-frame step (HIP events on every rank, same K everywhere): the shard kernel alone (no
+        # exchange), the exchange alone (nothing beside it), the whole step.  step - kernel = what the exchange costs on top of the
+        # kernel after overlap; kernel differences between ranks = the edge ranks' missing halo row or a slow GPU.
+        def rank_events(fn, k_steps):
+            for _ in range(8):
+                fn()
+            fence()
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(stream)
+            for _ in range(k_steps):
+                fn()
+            b_.record(stream)
+            fence()
+            return a_.elapsed_time(b_) / k_steps * 1e3           # us
+
+        breakdown = None
+        try:
+            kb = max(args.steps, 20)
+            hb0 = halo_bufs[0]
+            if fused:
+                kern_only = backend.bind_fused_rows(hb0, single_edge, rows, geom.top_is_border, geom.bottom_is_border)
+            else:
+                kern_only = backend.bind_sobel_rows(hb0, single_edge, rows, geom.top_is_border, geom.bottom_is_border)
+            us_kernel = rank_events(kern_only, kb)
+            us_exchange = None
+            if native is not None and not rehearsal_loopback:
+                up_p, dn_p = (rank - 1 if rank > 0 else -1), (rank + 1 if rank < world - 1 else -1)
+                nb_row = hb0[0].numel()
+                xfn = lambda: native.halo_exchange(up_p, hb0[1], hb0[0], dn_p, hb0[rows], hb0[rows + 1], nb_row, stream.cuda_stream)
+                us_exchange = rank_events(xfn, kb)
+            cnt_b = [0]
+
+            def step_b():
+                single_impl(cnt_b[0])
+                cnt_b[0] += 1
+            us_step = rank_events(step_b, kb)
+            mine = torch.tensor([us_kernel, us_exchange if us_exchange is not None else -1.0, us_step], dtype=torch.float64, device=device)
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            if rehearsal:
+                allr = [t_.cpu() for t_ in allr]
+                dist.all_gather(allr, mine.cpu())
+            else:
+                dist.all_gather(allr, mine)
+            rows_ = [[round(float(v), 1) for v in t_.tolist()] for t_ in allr]
+            breakdown = {"unit": "us per step, HIP events on each rank's stream", "steps": kb,
+                         "shard_kernel_alone": [r_[0] for r_ in rows_],
+                         "exchange_alone": [r_[1] if r_[1] >= 0 else None for r_ in rows_],
+                         "single_frame_step": [r_[2] for r_ in rows_],
+                         "exchange_not_hidden": [round(r_[2] - r_[0], 1) for r_ in rows_],
+                         "note": "step - kernel = what the halo exchange costs after overlap; exchange_alone is the unloaded RCCL group "
+                                 "(beside a bandwidth-bound kernel the same group takes ~3x as long: DESIGN.md section 6)"}
+        except Exception as exc:
+            breakdown = {"error": f"{type(exc).__name__}: {exc}"}
+
+        # (b) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
         host_shard = torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True)
         host_shard.copy_(rgbs[0])
         torch.cuda.synchronize()
@@ -807,10 +927,11 @@ def main() -> int:
             single_impl(k)
         k_e2e = max(1, min(args.steps, 20))
         forms["end_to_end_h2d"], _ = run_form(e2e_impl, k_e2e, "end_to_end_h2d")
-        # (a) a stream of frames, software-pipelined -- `value`
-        forms["pipelined"], elapsed = run_form(pipelined_impl, args.steps, "pipelined")
-        value = W * H_total * args.steps / elapsed / 1e6
-        step_ms_events = forms["pipelined"]["ms_per_step_events_rank0"]
+        # (c) a stream of frames, software-pipelined: another experiment (throughput of a stream, not the latency of one frame)
+        xc1 = native.exchange_count() if native is not None else 0
+        forms["pipelined"], _ = run_form(pipelined_impl, args.steps, "pipelined")
+        if native is not None:
+            forms["pipelined"]["exchanges_per_step"] = round((native.exchange_count() - xc1) / max(calls["pipelined"], 1), 3)
 
         # every rank's halo rows must hold its neighbours' edge rows (what the last pipelined step's exchange delivered)
         last = calls["pipelined"] - 1
@@ -826,6 +947,9 @@ def main() -> int:
         if rank < world - 1:
             halo_ok &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
         halo_ok = all_ranks_agree(halo_ok or rehearsal_loopback)
+        halo_timeouts = int(lib.gh_comm_halo_timeouts(native.handle)) if native is not None else 0
+        if not all_ranks_agree(halo_timeouts == 0):
+            halo_ok = False
 
         if not args.no_check and rank == 0 and not rehearsal_loopback:
             try:
@@ -845,22 +969,29 @@ def main() -> int:
                 check = f"unavailable ({type(exc).__name__})"
         bad = check == "MISMATCH" or not halo_ok or edge_sum_check.startswith("MISMATCH")
         if bad:
-            print(f"bench.py: parity check FAILED (check={check}, halo rows ok={halo_ok}, edge sum: {edge_sum_check})", file=sys.stderr)
+            print(f"bench.py: parity check FAILED (check={check}, halo rows ok={halo_ok}, halo-flag timeouts={halo_timeouts}, edge sum: {edge_sum_check})",
+                  file=sys.stderr)
             return 3
 
         bpp = 4 if fused else 6
         a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": ("gray_sobel_fused_rgb8" if fused else "gray_rgb8_to_plane+sobel3x3_u8")
-                    + " (per rank, pipelined step incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None}
+                    + " (per rank, single-frame step incl. halo exchange)", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "traffic_source": "not recorded for shards (the 1-GPU line carries the PMC figure of the same kernel)"}
         out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
-                    "step_pipelined_ms": forms["pipelined"]["ms_per_step"], "step_single_frame_ms": forms["single_frame"]["ms_per_step"],
+                    "step_single_frame_ms": forms["single_frame"]["ms_per_step"], "step_pipelined_ms": forms["pipelined"]["ms_per_step"],
                     "step_end_to_end_ms": forms["end_to_end_h2d"]["ms_per_step"], "step_forms": forms,
+                    "repeats": {"ms_per_step": [round(v, 4) for v in rep_ms], "min": round(min(rep_ms), 4),
+                                "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4), "max": round(max(rep_ms), 4),
+                                "note": "the K-step bracket of the single-frame form run again back to back; value / ms_per_step are the first entry"},
+                    "per_rank": breakdown, "exchange_fallback": native is None and args.exchange == "native",
+                    "exchange_issuer": "libgrayhip (csrc/comm.hip)" if native is not None else "torch.distributed", "halo_flag_timeouts": halo_timeouts,
                     "ms_per_step_events": step_ms_events, "edge_sum_check": edge_sum_check,
-                    "host_enqueue_us_per_step": forms["pipelined"]["host_enqueue_us_per_step"]})
+                    "host_enqueue_us_per_step": forms["single_frame"]["host_enqueue_us_per_step"]})
         halo = "RGB row (the fused kernel recomputes halo luma)" if fused else "luma row"
-        parallelism = (f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv; value = pipelined form "
-                       f"(stream of frames, ring of {NBUF}); single_frame and end_to_end_h2d forms in step_forms")
+        parallelism = (f"row-sharded x{world}; per step one {halo} is exchanged with each neighbour via RCCL send/recv; value = single-frame form "
+                       f"(ONE frame split {world} ways, BASELINE configs[3]); end_to_end_h2d and pipelined (stream of frames, ring of {NBUF}) in step_forms")
 
     if rank == 0:
         final = {
@@ -885,6 +1016,7 @@ def main() -> int:
             },
             "ranks": ranks_met,
             "rccl_ranks": rccl_ranks,
+            "exchange_fallback": False,
         }
         final.update(out)
         final.update({"parity_check": check, "halo_rows_check": "ok" if halo_ok else "MISMATCH", "settle_ms": args.settle_ms})

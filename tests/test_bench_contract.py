@@ -70,21 +70,52 @@ def test_pmc_summary_with_uneven_launch_counts_is_refused(tmp_path, monkeypatch)
     good = {"kernels": {"k_fused_dma": {"hbm_total_bytes": 1.11e9, "launches_averaged": [1200, 1300]}}}
     (prof / "pmc_hbm_traffic.json").write_text(json.dumps(good))
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    t, src = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
+    t, src, _ = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
     assert t == int(1.11e9) and src.endswith("pmc_hbm_traffic.json")
     bad = {"kernels": {"k_fused_dma": {"hbm_total_bytes": 1.2e9, "launches_averaged": [1174, 1]}}}
     (prof / "pmc_hbm_traffic.json").write_text(json.dumps(bad))
-    t, src = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
+    t, src, _ = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
     assert t is None and "refused" in src
+
+
+def test_recorded_traffic_is_withheld_when_the_run_does_not_look_like_the_profiled_one(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed PMC summary; it is reported only while the live launch matches the profile: same
+    device kernel, average duration within 5 % of the profiled average (scaled to the launch's pixel count)."""
+    b = load_bench()
+    prof = tmp_path / "profiles" / "rX"
+    prof.mkdir(parents=True)
+    (tmp_path / "profiles" / "LATEST").write_text("rX\n")
+    (prof / "pmc_hbm_traffic.json").write_text(json.dumps({"kernels": {"k_fused_dma": {"hbm_total_bytes": 1.11e9, "launches_averaged": [1200, 1300]}}}))
+    (prof / "kernel_stats.csv").write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"void (anonymous namespace)::k_fused_dma<0, 2, 2, 3, 0, 0>(unsigned char const*, unsigned char*)",2364,438927087,185671.35,30.28,180042,266442,6474.3\n'
+        '"void (anonymous namespace)::k_fused_dma<0, 3, 2, 3, 0, 1>(unsigned char const*, unsigned char*)",12,1,9000.0,0.01,1,1,1\n')
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    npx = 16384 * 16384
+    t, src, cross = b.measured_traffic("gray_sobel_fused_rgb8", npx, 0.1840, "k_fused_dma D=2")
+    assert t == int(1.11e9) and cross["ratio"] == pytest.approx(0.991, abs=2e-3) and cross["profiled_avg_us"] == pytest.approx(185.67, abs=0.01)
+    t, src, cross = b.measured_traffic("gray_sobel_fused_rgb8", npx, 0.2100, "k_fused_dma D=2")        # 13 % slower than profiled
+    assert t is None and "withheld" in src and cross["ratio"] > 1.05
+    t, src, cross = b.measured_traffic("gray_sobel_fused_rgb8", npx, 0.1840, "k_fused_stream")          # another kernel form ran
+    assert t is None and "not applicable" in src
+    t, src, cross = b.measured_traffic("gray_sobel_fused_rgb8", npx // 8, 0.1840 / 8, "k_fused_dma D=3")    # a shard: scaled by its pixels
+    assert t == int(1.11e9 / 8) and abs(cross["ratio"] - 0.991) < 2e-3
 
 
 def test_committed_pmc_summary_is_consistent():
     """What profiles/LATEST points at must pass bench.py's own guard and put the fused kernel's traffic near its
     algorithmic bytes (3 R + 1 W per pixel plus the halo rows of 64-row bands)."""
     b = load_bench()
-    t, src = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
+    t, src, _ = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384)
     assert t is not None, src
     assert 1.0 <= t / (4 * 16384 * 16384) < 1.08
+    # ... and the cross-check it is reported under must find the profiled symbol in the kernel statistics beside it
+    import csv
+    latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+    avg = [float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", latest, "kernel_stats.csv"))) if "::k_fused_dma<" in r["Name"]]
+    assert avg and 150e3 < max(avg) < 230e3
+    t, src, cross = b.measured_traffic("gray_sobel_fused_rgb8", 16384 * 16384, max(avg) / 1e6, "k_fused_dma D=2")
+    assert t is not None and cross["ratio"] == pytest.approx(1.0, abs=1e-3)
 
 
 @pytest.mark.gpu
@@ -102,5 +133,30 @@ def test_plain_command_runs_two_ranks_in_rehearsal():
     assert out["n_gpus"] == 2 and out["ranks"] == 2
     for k in ("step_single_frame_ms", "step_pipelined_ms", "step_end_to_end_ms"):
         assert out[k] > 0
+    # the headline of N > 1 is the configuration BASELINE configs[3] describes: ONE frame split N ways
+    assert out["ms_per_step"] == out["step_single_frame_ms"] == out["step_forms"]["single_frame"]["ms_per_step"]
+    assert out["value"] == pytest.approx(4096 * 2048 / (out["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
+    assert len(out["repeats"]["ms_per_step"]) == 5 and out["repeats"]["min"] <= out["repeats"]["median"] <= out["repeats"]["max"]
+    pr = out["per_rank"]
+    assert len(pr["shard_kernel_alone"]) == 2 and len(pr["single_frame_step"]) == 2 and all(v > 0 for v in pr["shard_kernel_alone"] + pr["single_frame_step"])
+    assert out["exchange_fallback"] is True and out["exchange_issuer"] == "torch.distributed"      # rehearsal: RCCL refuses two ranks on one device
+    assert out["halo_flag_timeouts"] == 0
     assert out["halo_rows_check"] == "ok" and out["parity_check"].startswith("ok")
     assert out["rehearsal"]
+
+
+@pytest.mark.gpu
+def test_loopback_rehearsal_drives_the_native_step_forms():
+    """GH_BENCH_REHEARSAL=loopback: every rank drives libgrayhip's own step code (halo-flag form, batched prefetch) with a private
+    one-rank communicator in loopback mode -- the bookkeeping the 8-GPU run relies on: one exchange per single-frame step, one per
+    BATCH frames in the pipelined form, no halo-flag timeout."""
+    env = dict(os.environ, GH_BENCH_REHEARSAL="loopback")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--width", "4096", "--height", "4096", "--steps", "8",
+                        "--warmup", "2", "--settle-ms", "30"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert out["exchange_fallback"] is False and out["exchange_issuer"].startswith("libgrayhip")
+    assert out["step_forms"]["single_frame"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.01)
+    assert out["step_forms"]["pipelined"]["exchanges_per_step"] <= 0.35            # four frames per exchange (+ the cold start)
+    assert out["halo_flag_timeouts"] == 0
