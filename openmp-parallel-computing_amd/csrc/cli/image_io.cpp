@@ -470,7 +470,14 @@ bool gh_image_write_png(const std::string &path, int width, int height, int chan
     // GRAYHIP_PNG=fast: band-parallel zlib deflate (any PNG reader decodes the same pixels, 3-10x faster to write);
     // default: the reference's own byte stream (one IDAT, stb's compressor restated above) -- files compare equal with cmp
     const char *pm = getenv("GRAYHIP_PNG");
-    const bool reference_bytes = !(pm && strcmp(pm, "fast") == 0) && (rb + 1) * (size_t)height < (1ull << 31);
+    const bool want_reference = !(pm && strcmp(pm, "fast") == 0);
+    const bool reference_bytes = want_reference && (rb + 1) * (size_t)height < (1ull << 31);
+    // Beyond 2 GiB of filtered bytes the reference's writer cannot be followed (its int arithmetic overflows: stb_image_write.h's
+    // stbi_zlib_compress takes `int data_len`), so the band-parallel encoder takes over: same pixels, other bytes.  Said once, on
+    // request only -- stderr stays empty on success for the bench script.
+    if (want_reference && !reference_bytes && getenv("GRAYHIP_VERBOSE"))
+        fprintf(stderr, "grayhip: %s: %zu filtered bytes exceed the reference writer's 2 GiB range; written with the band-parallel encoder "
+                        "(identical pixels, not the reference's byte stream)\n", path.c_str(), (rb + 1) * (size_t)height);
 
     // bands: >= 256 KiB of rows each, at most 4 per hardware thread; GH_PNG_THREADS caps the worker count
     const size_t band_bytes = 256 * 1024;

@@ -672,13 +672,8 @@ bool JpegDecoder::decode_scan()
     }
     // continue with the segments behind the entropy-coded data
     p_ = bits_.position();
-    if (const uint8_t m = bits_.pending_marker()) {       // the reader stopped AT a marker: hand it back to the segment loop
-        p_ -= 2;
-        if (p_[0] != 0xFF || p_[1] != m) {                // (fill bytes in between: rewind to the byte before the code)
-            p_ = bits_.position() - 1;
-            --p_;
-        }
-    }
+    if (bits_.pending_marker()) p_ -= 2;                   // the reader stopped right behind a marker's two bytes (fill bytes included:
+                                                          // it consumes 0xFF runs up to the code): hand the marker back to the segment loop
     return true;
 }
 

@@ -62,6 +62,27 @@ int do_init(int device)
     return GH_OK;
 }
 
+// The two streams of the chunked host pipelines (upload | kernel + download), created once per process.  Both or neither: a call
+// that found only one of them would run its other half on the NULL (blocking) stream without any error.
+int host_pipeline_streams(hipStream_t *up, hipStream_t *dn)
+{
+    static hipStream_t s_up = nullptr, s_dn = nullptr;       // callers hold g_host_mu
+    if (!s_up || !s_dn) {
+        hipStream_t a = nullptr, b = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            if (a) (void)hipStreamDestroy(a);
+            return gh_set_error(GH_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        }
+        s_up = a;
+        s_dn = b;
+    }
+    *up = s_up;
+    *dn = s_dn;
+    return GH_OK;
+}
+
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
     int start(hipStream_t s)
@@ -257,8 +278,8 @@ int gh_gray_passes_host(unsigned char *data, int width, int height, int channels
     const size_t chunk_px = (size_t)GH_TUNE_INT("GH_HOST_CHUNK_MPX", 16) << 20;          // multiple of 1024 px: whole wavefront groups
     if (nbytes >= ((size_t)GH_TUNE_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && chunk_px > 0 && npix > 2 * chunk_px) {
         const int nchunk = (int)((npix + chunk_px - 1) / chunk_px);
-        static hipStream_t s_up = nullptr, s_dn = nullptr;
-        if (!s_up) { GH_HIP_TRY(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)); GH_HIP_TRY(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking)); }
+        hipStream_t s_up = nullptr, s_dn = nullptr;
+        if (int rc = host_pipeline_streams(&s_up, &s_dn)) return rc;
         std::vector<hipEvent_t> up(nchunk, nullptr), k0(nchunk, nullptr), k1(nchunk, nullptr);
         auto cleanup = [&] { for (auto *v : {&up, &k0, &k1}) for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e); };
         for (int k = 0; k < nchunk; ++k)
@@ -290,6 +311,7 @@ int gh_gray_passes_host(unsigned char *data, int width, int height, int channels
             e = hipStreamWaitEvent(s_dn, up[k], 0);
             if (e != hipSuccess) break;
             e = hipEventRecord(k0[k], s_dn);
+            if (e != hipSuccess) break;
             rc = gh_gray_inplace_passes_dev(dev + p0 * channels, n, channels, mode, passes, s_dn);
             if (rc == GH_OK) e = hipEventRecord(k1[k], s_dn);
             if (rc == GH_OK && e == hipSuccess) e = hipMemcpyAsync(data + p0 * channels, dev + p0 * channels, n * channels, hipMemcpyDeviceToHost, s_dn);
@@ -347,8 +369,8 @@ int gh_sobel_edge_host(const unsigned char *src, unsigned char *dst, int width, 
     const int B = chunk_px ? (int)std::max<size_t>(64, chunk_px / (size_t)width) : 0;      // rows per chunk
     if (npix >= ((size_t)GH_TUNE_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && B > 0 && height > 2 * B) {
         const int nchunk = (height + B - 1) / B;
-        static hipStream_t s_up = nullptr, s_dn = nullptr;
-        if (!s_up) { GH_HIP_TRY(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)); GH_HIP_TRY(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking)); }
+        hipStream_t s_up = nullptr, s_dn = nullptr;
+        if (int rc = host_pipeline_streams(&s_up, &s_dn)) return rc;
         std::vector<hipEvent_t> up(nchunk, nullptr);
         auto cleanup = [&] { for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e); };
         for (int k = 0; k < nchunk; ++k)

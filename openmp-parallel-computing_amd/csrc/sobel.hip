@@ -889,7 +889,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 // (the second launch costs ~10 us: only where the first one is long -- 16384 x 16390 0.1076 ms this way, 0.1146 on the one-strip kernel;
                 //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
                 const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, GH_NUM_CU);
-                if (overflow2 && (long long)width * rows >= (1ll << 28)) {
+                if (overflow2 && (long long)width * rows >= (long long)GH_TUNE_INT("GH_SOBEL_SPLIT_MIN_PX", 1 << 28)) {
                     if (hw) return GH_NO_FLAG_FORM;
                     const int main_rows = rows - rows % R2;
                     if (int rc = gh_sobel_u8_rows_dev(src, dst, width, main_rows, top_is_border, 0, stream)) return rc;

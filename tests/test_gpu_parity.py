@@ -84,6 +84,14 @@ def test_known_answers_full_size(pkg, oracle, known, torch_mod, name):
     fused = pkg.hostapi.gray_sobel_fused(d, 0)
     assert torch_mod.equal(fused, edge)
     del fused, edge
+    # BASELINE configs[4]'s path at this size: the frame stays in HOST memory and goes through the band streamer (three hipStreams,
+    # bands of 4096 and of 1000 rows -- the second does not divide the height) -- same known answer
+    frame = make_frame(oracle, name, spec)
+    for tile_rows in ((4096, 1000) if name == "rand1_16384" else (4096,)):
+        edge_host = np.full((spec["h"], spec["w"]), 0x77, dtype=np.uint8)
+        pkg.hostapi.gray_sobel_streamed(frame, edge_host, tile_rows=tile_rows)
+        assert hashlib.sha256(edge_host.data).hexdigest() == want["edge"], tile_rows
+    del frame, edge_host
     assert pkg.hostapi.sum_rgb_dev(d) == known["channel_sums"][name]
     # FMA mode at full size (hash of the plane only)
     assert sha(pkg.hostapi.gray_to_plane(d, 1, out=gray)) == known["FMA"][name]["gray"]
@@ -824,8 +832,8 @@ def test_headline_shapes_run_the_kernels_they_are_meant_to_run(pkg, torch_mod):
 
 @pytest.mark.parametrize("w,h,band_rows", [(4096, 70, ""), (2048, 17, ""), (8192, 200, "64"), (8192, 65, "64"), (6160, 47, "16"), (2050, 35, "")])
 def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
-    """Rows that do not split into whole bands: k_sobel_dma2 takes the whole bands, the ragged rest goes through a second launch (the
-    one-strip kernel on a band with a real halo row above)."""
+    """Rows that do not split into whole bands: k_sobel_dma2 shifts its last band up to end at the frame edge (the shared rows are
+    computed twice).  (The two-launch split of very large frames is test_sobel_two_strips_split_into_two_launches.)"""
     monkeypatch.setenv("GH_SOBEL_NS", "2")
     if band_rows:
         monkeypatch.setenv("GH_SOBEL_R", band_rows)
@@ -835,6 +843,31 @@ def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_ro
     out = torch_mod.empty((h, w), dtype=torch_mod.uint8, device="cuda")
     pkg.hostapi.sobel_rows(d, out, h, False, False)
     assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane)[1:h + 1])
+
+
+@pytest.mark.parametrize("w,h", [(8192, 4101), (8192, 4111), (16384, 2050)])
+def test_sobel_two_strips_split_into_two_launches(pkg, oracle, torch_mod, w, h, monkeypatch):
+    """Frames whose whole bands fill the resident workgroup slots exactly and that have a few rows more: a shifted extra band would add
+    a layer of workgroups, so k_sobel_dma2 takes the whole bands (bottom edge: a real halo row) and a second launch the ragged rest
+    (top edge: a real halo row).  Production takes this path from 2^28 pixels up (16384 x 16390); GH_SOBEL_SPLIT_MIN_PX brings it
+    down to a frame the oracle finishes in a second.  Checked as a whole frame and as a band with halo rows on both sides."""
+    monkeypatch.setenv("GH_SOBEL_NS", "2")
+    monkeypatch.setenv("GH_SOBEL_R", "16")
+    monkeypatch.setenv("GH_SOBEL_SPLIT_MIN_PX", "1")
+    plane = oracle.frame_rand(w, h + 2, 1, seed=w + 7 * h).reshape(h + 2, w)
+    want = oracle.sobel(plane)
+    d = dev(torch_mod, plane)
+    assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1].contiguous()).cpu().numpy(), oracle.sobel(plane[1:h + 1]))
+    assert pkg.hostapi.last_kernel().startswith("k_sobel_dma")             # (the second launch: the one-strip kernel on the ragged rest)
+    for top, bot in ((False, False), (True, False), (False, True)):
+        out = torch_mod.full((h, w), 0x33, dtype=torch_mod.uint8, device="cuda")
+        pkg.hostapi.sobel_rows(d, out, h, top, bot)
+        ref = want[1:h + 1].copy()
+        if top or bot:
+            ref = oracle.sobel(plane[(1 if top else 0):(h + 1 if bot else h + 2)])[(0 if top else 1):][:h]
+        assert np.array_equal(out.cpu().numpy(), ref), (top, bot)
+    monkeypatch.setenv("GH_SOBEL_SPLIT_MIN_PX", str(1 << 30))              # the same frames without the split: shifted band or one-strip kernel
+    assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1].contiguous()).cpu().numpy(), oracle.sobel(plane[1:h + 1]))
 
 
 @pytest.mark.parametrize("w,h", [(2048, 16), (2049, 16), (2050, 32), (2051, 16), (2052, 48), (2060, 64), (4100, 32), (4099, 128), (6147, 16), (16370, 32), (16380, 64)])
