@@ -343,6 +343,8 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
 
     StateF2 st;
     st.clear();
+    const uint32_t first_col_mask = x == 0 ? 0xffffff00u : 0xffffffffu;
+    const uint32_t last_col_mask = x + 15 == w - 1 ? 0x00ffffffu : 0xffffffffu;
 
     const bool has_right = xw + STRIP_PX < w;                    // (wave-uniform) a pixel right of the strip exists
     auto strip_row = [&](int i) {                                // first byte of the strip in band row i (wave-uniform)
@@ -427,9 +429,9 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         else out = (j & 1) ? fused_row<MODE, CH, 1>(st, wv, hw, lane, half2) : fused_row<MODE, CH, 0>(st, wv, hw, lane, half2);
         if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
-            if (x == 0) out.x &= 0xffffff00u;
-            if (x + 15 == w - 1) out.w &= 0x00ffffffu;
-            if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+            out.x &= first_col_mask;                                 // the frame's first / last column is border: written as 0
+            out.w &= last_col_mask;
+            zero_if((y == 0 && zero_top) || (y == rows - 1 && zero_bot), out);
             if ((SP % 100) >= 20)      // access-pattern probe: same reads, but this workgroup's output rows written back to back
                 store_strip_p<(SP % 100) % 10>(edge + ((size_t)blockIdx.x * R + (i - 2)) * (WAVES_PER_BLOCK * STRIP_PX) + wave * STRIP_PX, lane, out);
             else

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 
     StateF2 st;
     st.clear();
+    const uint32_t first_col_mask = x == 0 ? 0xffffff00u : 0xffffffffu;
+    const uint32_t last_col_mask = x + 15 == w - 1 ? 0x00ffffffu : 0xffffffffu;
 
     const bool has_right = xw + STRIP_PX < w;                    // (wave-uniform) a pixel right of the strip exists
     auto strip_row = [&](int i) {                                // first byte of the strip in band row i (wave-uniform)
@@ -269,9 +271,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
         if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
-            if (x == 0) out.x &= 0xffffff00u;
-            if (x + 15 == w - 1) out.w &= 0x00ffffffu;
-            if ((y == 0 && zero_top) || (y == rows - 1 && zero_bot)) out = make_uint4(0, 0, 0, 0);
+            out.x &= first_col_mask;                                 // the frame's first / last column is border: written as 0
+            out.w &= last_col_mask;
+            zero_if((y == 0 && zero_top) || (y == rows - 1 && zero_bot), out);
             store_strip_p<SP>(dst + (size_t)y * w + xw, lane, out);
         }
         return false;
@@ -355,6 +357,8 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     StateF2 st0, st1;
     st0.clear();
     st1.clear();
+    const uint32_t first_col_mask = (xw + 16 * lane == 0) ? 0xffffff00u : 0xffffffffu;
+    const uint32_t last_col_mask = (xw + STRIP_PX + 16 * lane + 15 == w - 1) ? 0x00ffffffu : 0xffffffffu;
 
     const bool has_right = xw + SW < w;
     auto strip_row = [&](int i) {                                // first byte of the strip pair in band row i (wave-uniform)
@@ -405,7 +409,11 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         else hh = *reinterpret_cast<const uint2 *>(slotp + SW);
         const uint32_t sh = UNAL == 2 ? (uint32_t)(uintptr_t)strip_row(i) & 3u : 0u;     // the pair starts at byte sh of the lane grid
         const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
-        const bool zero_row = (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
+        // a frame-border row can only be a band's first or last output row: in the regular form those are two statically known steps
+        // (the steady chunks never see one), so the select below disappears from the steady loop
+        // (a band that walks upward -- a shard's first band with a real halo row above -- touches neither border row)
+        const bool may_be_border_row = !REG || (KIND == 3 && j == 2) || (KIND == 4 && j == CHK - 1);
+        const bool zero_row = may_be_border_row && ((y == 0 && zero_top) || (y == rows - 1 && zero_bot));
         auto strip = [&](auto sub_c, StateF2 &st, uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
             constexpr int SUB = decltype(sub_c)::value;
             uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
@@ -429,10 +437,9 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
             G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
             uint4 out = (j & 1) ? rowf2<1, 1>(st, G, half2) : rowf2<0, 1>(st, G, half2);
             if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {       // y < rows by construction of nrows
-                const int x = xw + SUB * STRIP_PX + 16 * lane;
-                if (SUB == 0 && x == 0) out.x &= 0xffffff00u;
-                if (SUB == 1 && x + 15 == w - 1) out.w &= 0x00ffffffu;
-                if (zero_row) out = make_uint4(0, 0, 0, 0);
+                if (SUB == 0) out.x &= first_col_mask;               // the frame's first / last column is border: written as 0
+                if (SUB == 1) out.w &= last_col_mask;
+                zero_if(zero_row, out);
                 store_strip_p<2>(dst + (size_t)y * w + xw + SUB * STRIP_PX, lane, out);
             }
         };
@@ -471,6 +478,119 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
 #pragma unroll 1
     for (; ch < nch; ++ch)
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
+}
+
+// ---- four strips per wave: 4 KiB of every row, packed-i16 state ------------------------------------------------------------------------
+// The no-arithmetic skeletons (DESIGN.md / NOTES.md) say a wave that owns 4 KiB of every row reads closer to a linear stream than one that
+// owns 1 or 2 KiB; the f32 pair state of k_sobel_dma2 (64 VGPRs per strip) stops at two strips.  The packed-i16 state (State16, 32 VGPRs
+// per strip) fits four: CORE 0 = row16 (scalar f32 magnitude, 10 VALU instructions per pixel), CORE 1 = row16p (packed f32 magnitude, 9.1)
+// against 8.4 for k_sobel_dma2.  Regular bands only (every band R + 2 input rows in whole chunks, the last one shifted up), aligned
+// frames at least 4096 columns wide; per row 5 DMA instructions (4 pieces + the halo dword) and 4 stores.
+template <int D, int CORE = 1>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
+                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
+{
+    using namespace stream_core;
+    constexpr int NS = 4, SW = NS * STRIP_PX;
+    constexpr int SLOT = SW + 16;
+    constexpr int CHK = (D % 2 == 0) ? D : 2 * D;
+    static_assert((2 * NS + 1) * (D - 1) <= 60, "vmcnt is 6 bits");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[WAVES_PER_BLOCK][D][SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int gx_i, gy_i;
+    band_of_block(plan, blockIdx.x, groups_x, gx_i, gy_i);
+    int xw = (gx_i * WAVES_PER_BLOCK + wave) * SW;
+    if (xw >= w) return;
+    if (xw + SW > w) xw = w - SW;                                // last group of strips: shifted left to end at the frame edge
+    if (gy_i < 0) return;
+    const int R = plan.R[0];
+    int y0 = gy_i * R;
+    if (y0 + R > rows) y0 = rows - R;           // the last band is shifted up to end at the frame edge (see k_sobel_dma)
+    const int nrows = R + 2;
+    const int nch = nrows / CHK;
+    const bool up = hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows;      // sharded step, halo-flag form: see k_fused_dma
+    if (hw.flag) gh_halo_started(hw);
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    const float half = half_reg();
+    const f32x2 half2 = half2_reg();
+    const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
+    uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
+    if ((lane == 0 && xw == 0) || (lane != 0 && xw + SW >= w)) hoff = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[wave][0][0];
+
+    State16 st[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st[k].clear();
+
+    auto strip_row = [&](int i) {                                // first byte of the wave's 4 KiB in band row i (wave-uniform)
+        const int yy = clamp_row(up ? y0 + nrows - 2 - i : y0 - 1 + i, rows, zero_top, zero_bot);
+        return uniform_ptr(src + (ptrdiff_t)yy * w + xw);
+    };
+    auto issue_row = [&](int i, int slot) {                      // always exactly 5 vector-memory instructions
+        if (hw.flag) {                                           // (wave-uniform) halo row of a shard: has the exchange landed?
+            const int raw = up ? y0 + nrows - 2 - i : y0 - 1 + i;
+            if ((raw < 0 && !zero_top) || (raw >= rows && !zero_bot)) gh_halo_wait(hw);
+        }
+        const uint32_t d = uniform_u32(lds0 + (uint32_t)slot * SLOT);
+        glds_row4k_halo(d, d + SW, strip_row(i) - xw, voff, hoff, slot);
+    };
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) issue_row(i, i);
+
+    // row step in the forms of a regular band (see k_sobel_dma2): 3 = first chunk (steps 0 and 1 store nothing), 1 = transition,
+    // 2 = steady, 4 = last chunk (its last D - 1 steps issue nothing).  Counted: the first and transition forms the DMA instructions of the
+    // D - 1 younger rows (5 each), the steady and last forms also their stores: 9 (D - 1).
+    auto row_step = [&](auto kind_c, int ch, int j) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int i = ch * CHK + j;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool issue = KIND == 4 ? j + D - 1 < CHK : true;       // (j is a constant in the unrolled chunk)
+        if (issue) {
+            issue_row(i + D - 1, (j + D - 1) % D);
+            if (KIND == 2 || KIND == 4) wait_vm<(2 * NS + 1) * (D - 1)>(j % D); else wait_vm<(NS + 1) * (D - 1)>(j % D);
+        } else {
+            wait_vm<0>(j % D);
+        }
+        const uint8_t *slotp = &ring[wave][j % D][0];
+        uint4 q[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) q[k] = *reinterpret_cast<const uint4 *>(slotp + k * STRIP_PX + 16 * lane);
+        const uint2 hh = *reinterpret_cast<const uint2 *>(slotp + SW);   // .x: the dword before the wave's bytes, .y: the dword behind them
+        const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
+        const bool zero_row = (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
+        const bool store = KIND == 3 ? j >= 2 : true;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            // the pixel left of strip k is strip k-1's last (lane 63, top byte of q.w), the pixel right of it strip k+1's first (lane 0, low byte of q.x)
+            const uint32_t left_of_lane0 = k == 0 ? hh.x : (uint32_t)__builtin_amdgcn_readlane((int)q[k > 0 ? k - 1 : 0].w, 63);
+            const uint32_t right_of_lane63 = k == NS - 1 ? hh.y : (uint32_t)__builtin_amdgcn_readfirstlane((int)q[k < NS - 1 ? k + 1 : 0].x);
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[k].w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[k].x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            if (lane == 0) ql = left_of_lane0;
+            if (lane == 63) qr = right_of_lane63;
+            uint4 out;
+            if (CORE == 0) out = (j & 1) ? row16<1>(st[k], q[k], ql, qr, half) : row16<0>(st[k], q[k], ql, qr, half);
+            else out = (j & 1) ? row16p<1>(st[k], q[k], ql, qr, half2) : row16p<0>(st[k], q[k], ql, qr, half2);
+            if (store) {
+                const int x = xw + k * STRIP_PX + 16 * lane;
+                if (k == 0 && x == 0) out.x &= 0xffffff00u;
+                if (k == NS - 1 && x + 15 == w - 1) out.w &= 0x00ffffffu;
+                if (zero_row) out = make_uint4(0, 0, 0, 0);
+                store_strip_p<2>(dst + (size_t)y * w + xw + k * STRIP_PX, lane, out);
+            }
+        }
+    };
+    auto chunk = [&](auto kind_c, int ch) {
+#pragma unroll
+        for (int j = 0; j < CHK; ++j) row_step(kind_c, ch, j);
+    };
+    chunk(std::integral_constant<int, 3>{}, 0);
+    int ch = 1;
+    if (CHK - 2 < D - 1) { chunk(std::integral_constant<int, 1>{}, 1); ch = 2; }
+#pragma unroll 1
+    for (; ch < nch - 1; ++ch) chunk(std::integral_constant<int, 2>{}, ch);
+    chunk(std::integral_constant<int, 4>{}, nch - 1);
 }
 
 #ifdef GH_ENABLE_PROBES
@@ -871,6 +991,26 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
             // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
             // 64-row bands when they still give every CU a workgroup, else 16.  GH_SOBEL_NS = 1: never, 2: whenever the geometry allows.
             const int ns_knob = GH_TUNE_INT("GH_SOBEL_NS", 0);
+            // Four strips per wave (k_sobel_dma4): on request only (GH_SOBEL_NS=4) -- measured against k_sobel_dma2 in NOTES.md.  Aligned frames
+            // of 4096 columns and more whose rows hold a whole band; GH_SOBEL_NS4_D ring depth (3, 2 or 6), GH_SOBEL_NS4_CORE 1 packed-f32
+            // magnitude / 0 the plain packed-i16 core, GH_SOBEL_R band height (64; R + 2 rows in whole chunks of the unroll).
+            if (ns_knob == 4 && aligned && dma == 3 && sp == 2 && width >= 4 * stream_core::STRIP_PX) {
+                const int d4 = GH_TUNE_INT("GH_SOBEL_NS4_D", 3), core4 = GH_TUNE_INT("GH_SOBEL_NS4_CORE", 1);
+                const int R4 = r_env > 0 ? r_env : 64, chk4 = d4 == 3 ? 6 : d4;
+                const int quads = (width + 4 * stream_core::STRIP_PX - 1) / (4 * stream_core::STRIP_PX), gx4 = (quads + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
+                if ((d4 == 2 || d4 == 3 || d4 == 6) && (R4 + 2) % chk4 == 0 && (R4 + 2) / chk4 >= 3 && rows >= R4) {
+                    if (hw && hw->pad) return GH_OK;
+                    stream_core::BandPlan p4 = stream_core::make_band_plan(rows, R4, -1, 0, -1, 0);
+                    p4.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p4.bands, gx4);
+                    const unsigned g4 = (unsigned)stream_core::plan_grid(p4, gx4);
+                    gh_note_kernel(core4 ? "k_sobel_dma4 packed-f32 magnitude" : "k_sobel_dma4");
+                    if (d4 == 2) { if (core4) k_sobel_dma4<2, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<2, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+                    else if (d4 == 6) { if (core4) k_sobel_dma4<6, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<6, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+                    else { if (core4) k_sobel_dma4<3, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<3, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+                    GH_LAUNCH_CHECK();
+                    return GH_OK;
+                }
+            }
             const int unal2 = aligned ? 0 : (GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
             if (unal2 >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
                 const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;

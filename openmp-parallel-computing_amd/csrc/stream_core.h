@@ -195,6 +195,52 @@ __device__ __forceinline__ uint4 rowf2(StateF2 &st, const f32x2 (&G)[10], f32x2 
 }
 
 
+// ---- packed-i16 state, packed-f32 magnitude ("hybrid") --------------------------------------------------------
+// row16's linear part (h1, h2, the rolling sums: 2 pixels per v_pk_*_i16, 32 state VGPRs per strip instead of the 64 of StateF2) with
+// the magnitude of rowf2 (v_pk_fma_f32 on integer-valued floats, v_sqrt_f32, v_cvt_pk_u8_f32 under RTZ).  Per 16 pixels: 17 v_perm +
+// 48 packed-i16 operations + 32 conversions + 16 v_pk_fma + 16 v_sqrt + 16 packs = 9.1 VALU instructions per pixel against 8.4 for the
+// all-f32 pair core and 10 for row16 -- the price of fitting FOUR strips' state into a wave's registers (k_sobel_dma4).
+template <int PAR>
+__device__ __forceinline__ uint4 row16p(State16 &st, const uint4 &qv, uint32_t ql, uint32_t qr, f32x2 half2)
+{
+    const uint32_t q[6] = {ql, qv.x, qv.y, qv.z, qv.w, qr};
+    s16x2 o[9], e[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t cur = q[j + 1];
+        e[2 * j] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c010c00u));        // (p[4j],   p[4j+1])
+        e[2 * j + 1] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c030c02u));    // (p[4j+2], p[4j+3])
+        o[2 * j] = as_s16x2(__builtin_amdgcn_perm(cur, q[j], 0x0c040c03u));      // (p[4j-1], p[4j])
+        o[2 * j + 1] = as_s16x2(__builtin_amdgcn_perm(0u, cur, 0x0c020c01u));    // (p[4j+1], p[4j+2])
+    }
+    o[8] = as_s16x2(__builtin_amdgcn_perm(q[5], q[4], 0x0c040c03u));             // (p[15], p[16])
+    uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const s16x2 h1 = o[k + 1] - o[k];
+        const s16x2 h2 = pk_mad2(e[k], o[k] + o[k + 1]);
+        const s16x2 c = st.h1p[k] + h1;
+        const s16x2 gx = st.cp[k] + c;
+        const s16x2 gy = st.h2r[PAR][k] - h2;
+        st.h1p[k] = h1; st.cp[k] = c; st.h2r[PAR][k] = h2;
+        const f32x2 fx = {(float)(int)gx.x, (float)(int)gx.y}, fy = {(float)(int)gy.x, (float)(int)gy.y};    // pixels 2k, 2k + 1
+        const f32x2 m = __builtin_elementwise_fma(fx, fx, __builtin_elementwise_fma(fy, fy, half2));          // exact: < 2^22
+        r[k >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_sqrtf(m.x), (2 * k) & 3, r[k >> 1]);
+        r[k >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_sqrtf(m.y), (2 * k + 1) & 3, r[k >> 1]);
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// `if (rare wave-uniform condition) out = 0` as a scalar branch around four v_mov instead of four v_cndmask on every row: the empty asm
+// keeps the optimiser from converting the branch into selects
+__device__ __forceinline__ void zero_if(bool uniform_cond, uint4 &out)
+{
+    if (__builtin_expect(uniform_cond, 0)) {
+        asm volatile("" ::: "memory");
+        out = make_uint4(0, 0, 0, 0);
+    }
+}
+
 // opaque(): stops the optimiser from proving a float is a small integer and rewriting the f32 adds as integer/SDWA ops
 __device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
 

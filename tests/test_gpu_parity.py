@@ -845,6 +845,29 @@ def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_ro
     assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane)[1:h + 1])
 
 
+@pytest.mark.parametrize("w,h", [(4096, 64), (4096, 130), (8192, 192), (16384, 64), (16384, 80), (4112, 64), (12288, 131), (5008, 70)])
+@pytest.mark.parametrize("depth,core,band_rows", [("3", "1", ""), ("3", "0", ""), ("6", "1", ""), ("2", "1", "32"), ("3", "1", "16"), ("2", "0", "16")])
+def test_sobel_four_strips_per_wave(pkg, oracle, torch_mod, w, h, depth, core, band_rows, monkeypatch):
+    """k_sobel_dma4 (on request: GH_SOBEL_NS=4): a wave owns FOUR neighbouring 1 KiB strips of every row on the packed-i16 state, with
+    the packed-f32 or the scalar magnitude; the pixels the strips exchange travel by v_readlane.  Whole frames (last band shifted up,
+    last group of strips shifted left) and bands with real halo rows; frames too short for a band fall back to the other kernels."""
+    monkeypatch.setenv("GH_SOBEL_NS", "4")
+    monkeypatch.setenv("GH_SOBEL_NS4_D", depth)
+    monkeypatch.setenv("GH_SOBEL_NS4_CORE", core)
+    if band_rows:
+        monkeypatch.setenv("GH_SOBEL_R", band_rows)
+    plane = oracle.frame_rand(w, h + 2, 1, seed=w + 3 * h).reshape(h + 2, w)
+    d = dev(torch_mod, plane)
+    assert np.array_equal(pkg.hostapi.sobel(d).cpu().numpy(), oracle.sobel(plane))
+    if h + 2 >= int(band_rows or 64):
+        assert pkg.hostapi.last_kernel().startswith("k_sobel_dma4")
+    out = torch_mod.full((h, w), 0x21, dtype=torch_mod.uint8, device="cuda")
+    pkg.hostapi.sobel_rows(d, out, h, False, False)
+    assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane)[1:h + 1])
+    pkg.hostapi.sobel_rows(d, out, h, True, False)
+    assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane[1:])[:h])
+
+
 @pytest.mark.parametrize("w,h", [(8192, 4101), (8192, 4111), (16384, 2050)])
 def test_sobel_two_strips_split_into_two_launches(pkg, oracle, torch_mod, w, h, monkeypatch):
     """Frames whose whole bands fill the resident workgroup slots exactly and that have a few rows more: a shifted extra band would add

@@ -254,7 +254,9 @@ def test_every_counted_wait_is_covered_on_every_path(device_asm):
         # the counts are the ones the source derives: A pieces per row (+1 output store per row in steady state), D - 1 rows
         t = template_ints(name)
         stores = 1
-        if "k_sobel_dma2" in name:
+        if "k_sobel_dma4" in name:
+            d, a, stores = t[0], 5, 4            # four strips per wave: 4 pieces + the halo dword, 4 stores per row
+        elif "k_sobel_dma2" in name:
             d, a, stores = t[0], 3, 2            # two strips per wave: 2 pieces + the halo dword, 2 stores per row
         elif "k_sobel_dma" in name or "k_conv3x3_dma" in name:
             d, a = t[0], 2
