@@ -412,6 +412,10 @@ def main() -> int:
     api, sharding = pkg.hostapi, pkg.sharding
     api.init(local_rank)
     lib = pkg.abi.load()
+    import ctypes as _C
+    _cu, _xcd = _C.c_int(0), _C.c_int(0)
+    pkg.abi.check(lib.gh_device_topology(_C.byref(_cu), _C.byref(_xcd)), "gh_device_topology")
+    device_topology = {"compute_units": _cu.value, "xcds": _xcd.value}       # what the launch rules size their plans for
     mode = pkg.MODE_FMA if args.mode == "fma" else pkg.MODE_IEEE
 
     W = args.width
@@ -1014,6 +1018,7 @@ def main() -> int:
                 "parallelism": parallelism,
                 "halo_exchange": exchange + (f" [{exchange_note}]" if exchange_note else ""),
             },
+            "device": device_topology,
             "ranks": ranks_met,
             "rccl_ranks": rccl_ranks,
             "exchange_fallback": False,

@@ -62,6 +62,9 @@ GH_API const char *gh_last_error(void);
  * "k_fused_dma D=2" ("" before the first launch).  Diagnostic: lets a test assert that a shape runs the kernel it is meant to run. */
 GH_API const char *gh_last_kernel(void);
 GH_API const char *gh_version(void);
+/* CU and XCD counts of the initialised device, as the launch rules use them (band heights and grid sizes are chosen in multiples of
+ * the CU count; MI355X in SPX mode: 256 / 8).  Initialises the library if needed. */
+GH_API int gh_device_topology(int *compute_units, int *xcds);
 GH_API int gh_default_mode(void);               /* GRAYHIP_MODE=ieee|fma, default ieee */
 
 GH_API int gh_malloc(void **dptr, size_t nbytes);

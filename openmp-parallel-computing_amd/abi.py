@@ -26,6 +26,7 @@ SIGNATURES = {
     "gh_last_error": (C.c_char_p, []),
     "gh_last_kernel": (C.c_char_p, []),
     "gh_version": (C.c_char_p, []),
+    "gh_device_topology": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gh_default_mode": (C.c_int, []),
     "gh_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "gh_free": (C.c_int, [C.c_void_p]),

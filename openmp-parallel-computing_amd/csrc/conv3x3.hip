@@ -369,8 +369,12 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         // 16384^2 0.2954 ms with 16-row bands against 0.3137 with 64, 16370 x 16384 0.3332-0.3391 vs 0.3559, 12288 x 4096 0.0606 vs 0.0796,
         // 7680 x 4352 0.0426 vs 0.0490; only 16384 x 4096 (0.0770 vs 0.0746) and 32768 x 8192 (32-row bands 0.2894, 16: 0.2974, 64: 0.3119)
         // have a slightly better height.  At 97 registers five workgroups fit a CU, so short bands do not starve it of waves.)
+        // Round 3 (tools/sweep.py conv_bands): 22-row bands -- 24 input rows = four whole chunks of the regular form, and band starts 22 rows
+        // apart fall on many channel phases where 16 x 48 KiB fall on four -- beat 16 on every shape tried: 16384^2 0.2851 vs 0.2956 ms
+        // (70.6 % vs 68.1 %), 16370 x 16384 0.3287 vs 0.3379, 16384 x 4096 0.0759 vs 0.0779, 7680 x 4320 0.0440 vs 0.0455, 12288^2 equal; 28 /
+        // 34 / 40 / 64 rows lose 3-7 %.  Where 22-row starts would alias and 16-row ones do not (stream_core::prefer_short_bands) 16 stays.
         int R = GH_TUNE_INT("GH_CONV_R", 0);
-        if (R <= 0) R = 16;
+        if (R <= 0) R = (height >= 22 && !(GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(wb, 22, 16))) ? 22 : 16;
         stream_core::BandPlan plan = stream_core::make_band_plan(height, R, -1, 0, -1, 0);
         // pairs-per-XCD dispatch order (8): 0.290 ms against 0.293 (band-per-XCD) / 0.294 (plain) on 16384^2, ahead on 16368 / 16370 too
         plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x);
@@ -380,7 +384,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
         // regular-band form: bands whose R + 2 input rows are whole chunks of 6 and into which the rows split (16- and 64-row bands)
         const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
-                         !stream_core::shifted_band_overflows(groups_x, height, R, 5, GH_NUM_CU);
+                         !stream_core::shifted_band_overflows(groups_x, height, R, 5, gh_num_cu());
         gh_note_kernel(reg ? (unal ? "k_conv3x3_dma regular unaligned" : "k_conv3x3_dma regular") : (unal ? "k_conv3x3_dma unaligned" : "k_conv3x3_dma"));
         if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
         else if (reg && unal == 1) k_conv3x3_dma<3, 1, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
@@ -401,7 +405,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         int R = GH_TUNE_INT("GH_CONV_R", 0);
         if (R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
-            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
+            R = nb64 >= 2 * gh_num_cu() ? 64 : (nb32 >= 2 * gh_num_cu() ? 32 : 16);
         }
         stream_core::BandPlan plan{};
         plan.bands = (height + R - 1) / R;

@@ -589,22 +589,7 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
         if (dma_ok) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
-                const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-                // tall bands re-read fewer halo rows, but between one and two workgroups per CU they only pay when the workgroups spread
-                // evenly over the CUs: 16384 x 4096 (256 workgroups of 64-row bands, one per CU) 0.0495 vs 0.0555 ms with 16-row bands, but
-                // 12288 x 8192 (384 = 1.5 per CU) 0.0887 vs 0.0813 with 32-row and 0.0771 with 16-row bands, 10240^2 (480) 0.0887 vs 0.0840 with
-                // 32 (tools/r2_call_bd.sh): "balance" = workgroups / (CUs x rounds needed)
-                auto balance = [](long long nb) { return stream_core::wg_balance(nb, GH_NUM_CU); };
-                rd = (nb64 >= 2 * GH_NUM_CU || (nb64 >= GH_NUM_CU && balance(nb64) >= 0.97)) ? 64
-                     : ((nb32 >= 2 * GH_NUM_CU && balance(nb32) >= 0.9) ? 32 : 16);
-                // band starts that alias onto a few channel phases (stream_core::prefer_short_bands): 10240 x 16384 0.1377 ms with 64-row
-                // bands, 0.1298 with 32; 12288 x 8192 0.0813 with 32, 0.0771 with 16
-                if (GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1)) {
-                    const long long pitch = (long long)width * channels;
-                    if (rd == 64 && stream_core::prefer_short_bands(pitch, 64, 32) && nb32 >= GH_NUM_CU) rd = 32;
-                    if (rd == 64 && stream_core::prefer_short_bands(pitch, 64, 16)) rd = 16;
-                    if (rd == 32 && stream_core::prefer_short_bands(pitch, 32, 16)) rd = 16;
-                }
+                rd = stream_core::fused_band_rows(groups_x, rows, (long long)width * channels, gh_num_cu(), GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0);
             }
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;
@@ -617,7 +602,7 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);
             int pad_kb = GH_TUNE_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU
             if (dma < 0) {
-                const bool big = g > 2u * GH_NUM_CU;
+                const bool big = g > 2u * gh_num_cu();
                 dma = big ? 2 : 3;
                 if (pad_kb < 0) pad_kb = big ? 30 : 0;               // 24.7 KiB ring + 30 KiB > 160 KiB / 3: two per CU
             }
@@ -631,7 +616,7 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
             // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
             // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/r2_call_ba.sh); aligned frames only
             const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows >= 16 && plan.n[1] == 0 && plan.order < 1000 &&
-                             !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, GH_NUM_CU);
+                             !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, gh_num_cu());
             gh_note_kernel(reg ? "k_fused_dma regular R=16" : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
             if (reg) {
                 launch_fused_dma<3, 2, 0, 1>(L);
@@ -672,7 +657,7 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
         int pick = variant;
         if (pick == 0) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-            pick = nb64 >= 4 * GH_NUM_CU ? 64 : (nb32 >= 4 * GH_NUM_CU ? 32 : 16);     // >= 4 workgroups per CU
+            pick = nb64 >= 4 * gh_num_cu() ? 64 : (nb32 >= 4 * gh_num_cu() ? 32 : 16);     // >= 4 workgroups per CU
         }
         switch (pick) {
         case 64: GH_FUSED_LAUNCH(64, 2, 1); break;

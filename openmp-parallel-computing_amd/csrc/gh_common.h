@@ -65,9 +65,14 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
 
 static inline bool gh_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// MI355X: 256 CUs in 8 XCDs
-constexpr int GH_NUM_CU = 256;
-constexpr int GH_NUM_XCD = 8;
+// Topology the launch rules work with: the CU and XCD counts of the initialised device (gh_init reads them; shim.hip).  The rules were
+// measured on an MI355X in SPX mode -- 256 CUs in 8 XCDs, the values before initialisation -- and are written in multiples of the CU count,
+// so a partitioned device (CPX: 32 CUs, one XCD) gets plans sized for what it has.  GH_NUM_CU_OVERRIDE (environment): pretend another CU
+// count (launch-rule experiments).  The workgroup -> band mappings that interleave over XCDs (band_of_block) assume 8 dispatch queues;
+// with another XCD count they are still permutations -- every band is processed exactly once -- only the locality they aim at is lost.
+constexpr int GH_REF_NUM_CU = 256, GH_REF_NUM_XCD = 8;
+int gh_num_cu();
+int gh_num_xcd();
 
 // ---- device-side arithmetic shared by every kernel ---------------------------------------------
 #if defined(__HIPCC__)

@@ -25,6 +25,7 @@ thread_local const char *g_last_kernel = "";
 std::once_flag g_init_once;
 int g_init_rc = GH_OK;
 int g_device = -1;
+int g_num_cu = GH_REF_NUM_CU, g_num_xcd = GH_REF_NUM_XCD;
 char g_init_err[768] = "";     // why initialisation failed, for threads other than the one that tried
 
 // grow-only device scratch for the host-pointer entry points (caller threads are serialised)
@@ -59,6 +60,11 @@ int do_init(int device)
     GH_HIP_TRY(hipSetDevice(device));
     GH_HIP_TRY(hipFree(nullptr));   // force context creation
     g_device = device;
+    // topology for the launch rules (gh_common.h): what the device reports, not constants
+    g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : GH_REF_NUM_CU;
+    int xcc = 0;
+    g_num_xcd = (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xcc > 0) ? xcc : GH_REF_NUM_XCD;
+    (void)hipGetLastError();
     return GH_OK;
 }
 
@@ -111,6 +117,13 @@ struct EventTimer {
 }  // namespace
 
 void gh_note_kernel(const char *name) { g_last_kernel = name; }
+
+int gh_num_cu()
+{
+    static const int forced = [] { const char *e = getenv("GH_NUM_CU_OVERRIDE"); return e ? atoi(e) : 0; }();
+    return forced > 0 ? forced : g_num_cu;
+}
+int gh_num_xcd() { return g_num_xcd; }
 
 int gh_set_error(int status, const char *fmt, ...)
 {
@@ -169,6 +182,14 @@ const char *gh_last_error(void) { return g_err; }
 const char *gh_last_kernel(void) { return g_last_kernel; }
 
 const char *gh_version(void) { return "grayhip 0.1 (gfx950)"; }
+
+int gh_device_topology(int *compute_units, int *xcds)
+{
+    if (int rc = gh_ensure_init()) return rc;
+    if (compute_units) *compute_units = gh_num_cu();
+    if (xcds) *xcds = gh_num_xcd();
+    return GH_OK;
+}
 
 int gh_default_mode(void)
 {

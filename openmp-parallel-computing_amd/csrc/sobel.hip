@@ -956,15 +956,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
         int R = r_env;
         // the LDS-DMA kernel takes any band height (tuning knob); the register-staged one is instantiated for 16 / 32 / 64
         if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64) {
-            const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
-            // measured on MI355X (16384-wide planes, tools/ab_fused.py --op sobel): 64-row bands win from 8192 rows up
-            // (66-67 % of 8 TB/s vs 59-61 % for 32 / 16), 32 at 4096 rows, 16 below
-            R = nb64 >= 2 * GH_NUM_CU ? 64 : (nb32 >= 2 * GH_NUM_CU ? 32 : 16);
-            // tall bands whose starts alias onto a few channel phases lose to 16-row bands (stream_core::prefer_short_bands)
-            if (R == 64 && use_dma && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R = 16;
-            // ... except that the ring kernel has a branch-free "regular band" form for 16-row bands (below), which beats the 32-row
-            // choice wherever it applies: 12288 x 8192 0.0380 vs 0.0460 ms, 16384 x 4096 0.0301 vs 0.0309 (tools/r2_call_ay.sh)
-            if (R == 32 && use_dma && rows >= 16 && GH_TUNE_INT("GH_SOBEL_REG", 1) && !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, GH_NUM_CU)) R = 16;
+            R = stream_core::sobel_band_rows(groups_x, rows, width, gh_num_cu(), use_dma, GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0, GH_TUNE_INT("GH_SOBEL_REG", 1) != 0);
         }
         const long long nb = (long long)groups_x * ((rows + R - 1) / R);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
@@ -1017,18 +1009,18 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 // 64-row bands from one workgroup per CU up -- below two per CU only when they spread evenly over the CUs (16384 x 12288: 384
                 // workgroups, 0.0863 ms against 0.0749 with 16-row bands)
                 const long long nb64_2 = (long long)gx2 * (rows / 64);
-                const bool even64 = nb64_2 >= 2 * GH_NUM_CU || (nb64_2 >= GH_NUM_CU && stream_core::wg_balance(nb64_2, GH_NUM_CU) >= 0.97);
+                const bool even64 = nb64_2 >= 2 * gh_num_cu() || (nb64_2 >= gh_num_cu() && stream_core::wg_balance(nb64_2, gh_num_cu()) >= 0.97);
                 int R2 = r_env > 0 ? r_env : (even64 ? 64 : 16);
                 if (r_env <= 0 && R2 == 64 && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R2 = 16;
                 const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
                 // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
                 //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips)
-                const bool wanted = ns_knob == 2 || (unal2 == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * GH_NUM_CU);
+                const bool wanted = ns_knob == 2 || (unal2 == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * gh_num_cu());
                 // rows that do not split into whole bands: the kernel shifts the last band up -- unless the whole bands fill the 512 resident
                 // slots exactly; then the whole bands here and the ragged rest (fewer than R2 rows, real halo row above) in a second launch
                 // (the second launch costs ~10 us: only where the first one is long -- 16384 x 16390 0.1076 ms this way, 0.1146 on the one-strip kernel;
                 //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
-                const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, GH_NUM_CU);
+                const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, gh_num_cu());
                 if (overflow2 && (long long)width * rows >= (long long)GH_TUNE_INT("GH_SOBEL_SPLIT_MIN_PX", 1 << 28)) {
                     if (hw) return GH_NO_FLAG_FORM;
                     const int main_rows = rows - rows % R2;
@@ -1070,7 +1062,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
             // 3840 x 2160 0.0108 vs 0.0119, 1920 x 1088 0.0100 vs 0.0107); with 64-row bands on large frames it only lets a third workgroup
             // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.  GH_SOBEL_REG=0: never.
             const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows >= R && plan.n[1] == 0 && plan.order < 1000 &&
-                              !stream_core::shifted_band_overflows(groups_x, rows, R, 3, GH_NUM_CU);
+                              !stream_core::shifted_band_overflows(groups_x, rows, R, 3, gh_num_cu());
             gh_note_kernel(reg1 ? (unal ? "k_sobel_dma regular R=16 unaligned" : "k_sobel_dma regular R=16") : (unal ? "k_sobel_dma unaligned" : "k_sobel_dma"));
             if (reg1) {
                 if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);

@@ -570,6 +570,37 @@ inline bool shifted_band_overflows(long long groups_x, int rows, int R, int /*wg
     return layers_all > layers_full && layers_full < 8;
 }
 
+// ---- band height of the ring kernels: pure functions of the geometry and the device's CU count (fused.hip / sobel.hip call them with
+// gh_num_cu(); tests/native/launch_rules_dump.hip prints them for 256 and 32 CUs) --------------------------------------------------------
+// Fused kernel: tall bands re-read fewer halo rows, but between one and two workgroups per CU they only pay when the workgroups spread
+// evenly over the CUs (16384 x 4096: 256 workgroups of 64-row bands, one per CU, 0.0495 vs 0.0555 ms with 16-row bands; 12288 x 8192:
+// 384 = 1.5 per CU, 0.0887 vs 0.0813 with 32-row and 0.0771 with 16-row bands; 10240^2: 480, 0.0887 vs 0.0840 with 32) -- "balance" =
+// workgroups / (CUs x rounds needed); band starts that alias onto a few channel phases are demoted (prefer_short_bands: 10240 x 16384
+// 0.1377 ms with 64-row bands, 0.1298 with 32; 12288 x 8192 0.0813 with 32, 0.0771 with 16).
+inline int fused_band_rows(int groups_x, int rows, long long pitch_bytes, int num_cu, bool alias_rule)
+{
+    const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+    int rd = (nb64 >= 2ll * num_cu || (nb64 >= num_cu && wg_balance(nb64, num_cu) >= 0.97)) ? 64
+             : ((nb32 >= 2ll * num_cu && wg_balance(nb32, num_cu) >= 0.9) ? 32 : 16);
+    if (alias_rule) {
+        if (rd == 64 && prefer_short_bands(pitch_bytes, 64, 32) && nb32 >= num_cu) rd = 32;
+        if (rd == 64 && prefer_short_bands(pitch_bytes, 64, 16)) rd = 16;
+        if (rd == 32 && prefer_short_bands(pitch_bytes, 32, 16)) rd = 16;
+    }
+    return rd;
+}
+// Plane Sobel, one strip per wave: 64-row bands from two workgroups per CU up (16384-wide planes: 66-67 % of 8 TB/s from 8192 rows up
+// against 59-61 % for 32 / 16), else 32, else 16; an aliasing 64 is demoted to 16; where the branch-free regular form of 16-row bands
+// applies it beats the 32-row choice (12288 x 8192 0.0380 vs 0.0460 ms, 16384 x 4096 0.0301 vs 0.0309).
+inline int sobel_band_rows(int groups_x, int rows, long long pitch_bytes, int num_cu, bool ring_kernel, bool alias_rule, bool regular_form)
+{
+    const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+    int R = nb64 >= 2ll * num_cu ? 64 : (nb32 >= 2ll * num_cu ? 32 : 16);
+    if (R == 64 && ring_kernel && alias_rule && prefer_short_bands(pitch_bytes, 64, 16)) R = 16;
+    if (R == 32 && ring_kernel && rows >= 16 && regular_form && !shifted_band_overflows(groups_x, rows, 16, 3, num_cu)) R = 16;
+    return R;
+}
+
 // host side: workgroups to launch for a plan (the band-per-XCD order pads the band count to a multiple of 8: surplus
 // workgroups find gy < 0 and exit)
 inline long long plan_grid(const BandPlan &plan, int groups_x)

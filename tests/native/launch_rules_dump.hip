@@ -17,5 +17,15 @@ int main()
     for (long long nb : nbs) printf("balance %lld %.6f\n", nb, stream_core::wg_balance(nb, 256));
     const int shapes[][3] = {{2, 8200, 64}, {2, 16390, 64}, {2, 8192, 64}, {1, 4100, 16}, {2, 4320, 16}, {1, 1080, 16}, {2, 3000, 16}, {3, 8200, 16}, {4, 4100, 16}, {4, 100000, 16}};
     for (const auto &s : shapes) printf("overflow %d %d %d %d\n", s[0], s[1], s[2], (int)stream_core::shifted_band_overflows(s[0], s[1], s[2], 2, 256));
+    // band heights the launchers pick (stream_core::fused_band_rows / sobel_band_rows) for a device with `cus` compute units:
+    // "rows_fused cus width rows R" (RGB8: pitch 3 w, a workgroup spans 4096 columns), "rows_sobel cus width rows R"
+    const int frames[][2] = {{16384, 16384}, {16384, 8192}, {16384, 4096}, {16384, 2048}, {12288, 8192}, {10240, 16384}, {4096, 2048}, {4096, 4096},
+                             {2048, 2048}, {1920, 1080}, {8192, 1024}, {16384, 512}};
+    for (int cus : {256, 32, 304})
+        for (const auto &f : frames) {
+            const int gx = (f[0] + 4095) / 4096;
+            printf("rows_fused %d %d %d %d\n", cus, f[0], f[1], stream_core::fused_band_rows(gx, f[1], 3ll * f[0], cus, true));
+            printf("rows_sobel %d %d %d %d\n", cus, f[0], f[1], stream_core::sobel_band_rows(gx, f[1], f[0], cus, true, true, true));
+        }
     return 0;
 }

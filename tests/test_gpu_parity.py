@@ -811,6 +811,10 @@ def test_headline_shapes_run_the_kernels_they_are_meant_to_run(pkg, torch_mod):
     def fused(w, h, c=3):
         api.gray_sobel_fused(t.zeros((h, w, c), dtype=t.uint8, device="cuda"), 0)
         return api.last_kernel()
+    import ctypes
+    cu, xcd = ctypes.c_int(0), ctypes.c_int(0)
+    pkg.abi.check(pkg.abi.load().gh_device_topology(ctypes.byref(cu), ctypes.byref(xcd)), "gh_device_topology")
+    assert (cu.value, xcd.value) == (256, 8), "the choices below are the rules' answers for an MI355X in SPX mode"
     assert sobel(16384, 16384) == "k_sobel_dma2 regular R=64"          # BASELINE configs[2]: two strips per wave, 64-row bands
     assert sobel(16384, 2048) == "k_sobel_dma2 regular R=16"           # the shard of 8 GPUs
     assert sobel(12288, 8192) == "k_sobel_dma regular R=16"            # off-step width: one strip, regular 16-row bands
