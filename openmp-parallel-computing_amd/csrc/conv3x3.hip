@@ -365,7 +365,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
     if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_TUNE_INT("GH_CONV_DMA", 1)) {
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);
-        // Band height: 16 rows.  (This kernel had inherited the Sobel kernels' 64 / 32 / 16 rule untested.  Measured, tools/r2_call_bb.sh, bc:
+        // Band height: 16 rows.  (This kernel had inherited the Sobel kernels' 64 / 32 / 16 rule untested.  Measured, tools/sweep.py r2_bb, bc:
         // 16384^2 0.2954 ms with 16-row bands against 0.3137 with 64, 16370 x 16384 0.3332-0.3391 vs 0.3559, 12288 x 4096 0.0606 vs 0.0796,
         // 7680 x 4352 0.0426 vs 0.0490; only 16384 x 4096 (0.0770 vs 0.0746) and 32768 x 8192 (32-row bands 0.2894, 16: 0.2974, 64: 0.3119)
         // have a slightly better height.  At 97 registers five workgroups fit a CU, so short bands do not starve it of waves.)

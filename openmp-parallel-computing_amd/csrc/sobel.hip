@@ -977,8 +977,8 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
             // frames with unaligned rows: GH_SOBEL_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_sobel_dma, UNAL), 1 = pieces
             // from the strip's own unaligned address, 0 = register-staged strips + column tail (further down)
             // Two strips per wave (k_sobel_dma2, regular-band form): frames whose rows split into whole bands of 64 or 16 rows
-            // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/r2_call_ai.sh,
-            // r2_call_aj.sh): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
+            // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/sweep.py r2_ai,
+            // sweep.py r2_aj): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
             // 0.0521 / 0.0262 vs 0.0309 / 0.0166 vs 0.0185, 8192^2 0.0270 vs 0.0288, 7680 x 4352 0.0230 vs 0.0246; narrow or small
             // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
             // 64-row bands when they still give every CU a workgroup, else 16.  GH_SOBEL_NS = 1: never, 2: whenever the geometry allows.

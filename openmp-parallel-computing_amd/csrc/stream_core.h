@@ -530,7 +530,7 @@ __device__ __forceinline__ bool band_walks_up(const BandPlan &plan, int gy) { re
 
 // ---- band height and channel aliasing (host side) ----------------------------------------------------------------------------------
 // The bands of a strip kernel start R * pitch bytes apart, and the ~256 row streams in flight advance together.  Measured on MI355X
-// (tools/r2_call_bg.sh: plane Sobel, R = 64 against R = 16): where the band starts take only a FEW distinct values modulo 1 MiB the
+// (tools/sweep.py r2_bg: plane Sobel, R = 64 against R = 16): where the band starts take only a FEW distinct values modulo 1 MiB the
 // streams pile onto the same channels -- 12288-wide planes (64 rows = 768 KiB: 4 values) 0.0872 vs 0.0753 ms, 24576 wide (1.5 MiB: 2) 0.0910
 // vs 0.0755, 20480 wide (1.25 MiB: 4) 0.0785 vs 0.0633, 10240 wide (640 KiB: 8) 0.0864 vs 0.0681, 12288^2 0.0805 vs 0.0570 -- while ONE value
 // (16384- and 32768-wide planes: whole MiB, the address hash spreads the streams by their high bits) and MANY values (16368 / 16370 wide)

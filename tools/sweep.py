@@ -11,6 +11,8 @@ import json, os, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RECIPES = json.load(open(os.path.join(ROOT, "tools", "sweeps.json")))
+# round 2's sixty-seven one-off call scripts (tools/r2_call_<x>.sh), folded in as recipes r2_<x>: same commands, one runner
+RECIPES.update(json.load(open(os.path.join(ROOT, "tools", "sweeps_r2.json"))))
 
 
 def main():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launches the fused and the plane-Sobel kernel N times each on a W x H frame (developer tool; run under rocprofv3 --pmc ...,
-once per width, to compare the memory-pipeline counters of aligned and unaligned row pitches: tools/r2_call_s.sh)."""
+once per width, to compare the memory-pipeline counters of aligned and unaligned row pitches: tools/sweep.py r2_s)."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
