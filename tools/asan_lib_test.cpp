@@ -101,6 +101,37 @@ int main() {
         OK(gh_free(b4));
     }
     OK(gh_stream_sync(nullptr));
+    {   // round 3: the three forms of the single-frame step, the sharded convolution, the multi-pass pipeline, min / max, counters, topology
+        const unsigned long long x0 = gh_comm_exchange_count(comm);
+        for (const char *form : {"2", "1", "0", "2"}) {
+            setenv("GH_SHARD_STEP_FORM", form, 1);
+            for (int k = 0; k < 3; ++k) OK(gh_sharded_fused_step_dev(comm, (uint8_t *)bufs[k % 3], (uint8_t *)edge, w, rows, 3, 0, nullptr));
+        }
+        unsetenv("GH_SHARD_STEP_FORM");
+        void *luma = nullptr, *conv_out = nullptr, *mm = nullptr;
+        OK(gh_malloc(&luma, (size_t)(rows + 2) * w));
+        OK(gh_malloc(&conv_out, (size_t)rows * w * 3));
+        OK(gh_malloc(&mm, 8));
+        OK(gh_memset_dev(luma, 9, (size_t)(rows + 2) * w, nullptr));
+        OK(gh_sharded_sobel_step_dev(comm, (uint8_t *)luma, (uint8_t *)edge, w, rows, nullptr));
+        const int32_t gauss[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+        OK(gh_sharded_conv3x3_step_dev(comm, (uint8_t *)bufs[0], (uint8_t *)conv_out, w, rows, gauss, 16, nullptr));
+        OK(gh_conv3x3_rgb8_rows_dev((const uint8_t *)bufs[1] + (size_t)w * 3, (uint8_t *)conv_out, w, rows, gauss, 16, 0, 0, nullptr));
+        OK(gh_sharded_pipeline_gray_sobel_dev(comm, (uint8_t *)bufs[2], w, rows, 3, 3, 0, (uint8_t *)luma, (uint8_t *)edge, nullptr));
+        const int32_t init[2] = {256, -1};
+        OK(gh_copy_h2d(mm, init, 8, nullptr));
+        OK(gh_mean_gray_minmax_dev((const uint8_t *)bufs[0], (uint8_t *)conv_out, (size_t)rows * w, (int32_t *)mm, nullptr));
+        OK(gh_comm_allreduce_minmax_i32_dev(comm, (int32_t *)mm, nullptr));
+        OK(gh_stream_sync(nullptr));
+        if (gh_comm_exchange_count(comm) - x0 != 12 + 1 + 1 + 3) { printf("FAIL exchange count %llu\n", gh_comm_exchange_count(comm) - x0); return 1; }
+        if (gh_comm_halo_timeouts(comm) != 0) { printf("FAIL halo-flag wait timed out\n"); return 1; }
+        int cu = 0, xcd = 0;
+        OK(gh_device_topology(&cu, &xcd));
+        if (cu <= 0 || xcd <= 0) { printf("FAIL topology %d %d\n", cu, xcd); return 1; }
+        if (gh_sharded_conv3x3_step_dev(comm, (uint8_t *)bufs[0], (uint8_t *)conv_out, w, rows, nullptr, 16, nullptr) == 0) { printf("FAIL null kernel accepted\n"); return 1; }
+        OK(gh_free(luma)); OK(gh_free(conv_out)); OK(gh_free(mm));
+    }
+    OK(gh_stream_sync(nullptr));
     OK(gh_comm_destroy(comm));
     for (auto &p : bufs) OK(gh_free(p));
     OK(gh_free(edge));
