@@ -615,9 +615,10 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
                              : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
             // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
             // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/sweep.py r2_ba); aligned frames only
-            const bool reg = GH_TUNE_INT("GH_FUSED_REG", 1) && sp == 2 && dma == 3 && unal == 0 && R_ == 16 && rows >= 16 && plan.n[1] == 0 && plan.order < 1000 &&
-                             !stream_core::shifted_band_overflows(groups_x, rows, 16, 3, gh_num_cu());
-            gh_note_kernel(reg ? "k_fused_dma regular R=16" : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
+            const int reg_knob = GH_TUNE_INT("GH_FUSED_REG", 1);     // 2: also tall bands whose R + 2 rows are whole chunks of 6 (experiment, NOTES.md R3.5)
+            const bool reg = reg_knob && sp == 2 && dma == 3 && unal == 0 && (R_ == 16 || (reg_knob == 2 && (R_ + 2) % 6 == 0)) && rows >= R_ && plan.n[1] == 0 &&
+                             plan.order < 1000 && !stream_core::shifted_band_overflows(groups_x, rows, R_, 3, gh_num_cu());
+            gh_note_kernel(reg ? (R_ == 16 ? "k_fused_dma regular R=16" : "k_fused_dma regular") : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
             if (reg) {
                 launch_fused_dma<3, 2, 0, 1>(L);
             } else if (sp == 2 && unal) {
