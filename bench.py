@@ -487,6 +487,7 @@ def main() -> int:
 
     # N > 1: who issues the halo exchange.  native = libgrayhip's own RCCL communicator, whole step in one C++ call.
     native, exchange, exchange_note = None, "none", ""
+    step_form = None
     comms_to_close = []
     rccl_ranks = None
     if world > 1:
@@ -520,6 +521,11 @@ def main() -> int:
                                                    "n_gpus": world, "error": msg, "ranks": ranks_met, "rccl_ranks": rccl_ranks,
                                                    "exchange_fallback": True}) + "\n").encode())
                 dist.barrier()
+                for comm in comms_to_close:
+                    try:
+                        comm.close()
+                    except Exception:
+                        pass
                 dist.destroy_process_group()
                 return 4
 
@@ -791,9 +797,28 @@ def main() -> int:
                     native_step(k)
                     torch.cuda.synchronize()
                     same = same and bool(torch.equal(edge_native, runners[k % NBUF].edge))
-                native_single(0)
-                torch.cuda.synchronize()
-                same = same and bool(torch.equal(edge_native, runners[0].edge))
+                # the single-frame step (`value`): libgrayhip's default form (halo flag) three times over; should it disagree with
+                # torch.distributed on any rank, every rank switches to the serial form (exchange, then launch) and checks again
+                def single_agrees():
+                    good = True
+                    try:
+                        for _ in range(3):
+                            native_single(0)
+                            torch.cuda.synchronize()
+                            good = good and bool(torch.equal(edge_native, runners[0].edge))
+                    except Exception as exc_:
+                        print(f"bench.py: rank {rank}: single-frame step failed: {exc_}", file=sys.stderr)
+                        good = False
+                    return all_ranks_agree(good or rehearsal_loopback)
+
+                step_form = int(os.environ.get("GH_SHARD_STEP_FORM", "2"))
+                single_ok = single_agrees()
+                if not single_ok and step_form != 1:
+                    native.set_step_form(1)
+                    step_form = 1
+                    single_ok = single_agrees()
+                    exchange_note = "the halo-flag form of the single-frame step disagreed with torch.distributed; serial form (exchange, then launch) in its place"
+                same = same and single_ok
                 same_b = False
                 if same and fused and bstep is not None:
                     same_b = True
@@ -991,6 +1016,8 @@ def main() -> int:
                                 "note": "the K-step bracket of the single-frame form run again back to back; value / ms_per_step are the first entry"},
                     "per_rank": breakdown, "exchange_fallback": native is None and args.exchange == "native",
                     "exchange_issuer": "libgrayhip (csrc/comm.hip)" if native is not None else "torch.distributed", "halo_flag_timeouts": halo_timeouts,
+                    "shard_step_form": ({2: "halo flag (exchange on a side stream beside one launch; edge bands wait for a flag)", 1: "serial (exchange, then one launch)",
+                                         0: "events (exchange || interior rows, then edge rows)"}.get(step_form) if native is not None else None),
                     "ms_per_step_events": step_ms_events, "edge_sum_check": edge_sum_check,
                     "host_enqueue_us_per_step": forms["single_frame"]["host_enqueue_us_per_step"]})
         halo = "RGB row (the fused kernel recomputes halo luma)" if fused else "luma row"

@@ -205,6 +205,9 @@ GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
  * Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
  *   fused: buf = interleaved RGB8/RGBA8 rows, the halo is one RGB row (the luma plane never exists in HBM)
  *   sobel: buf = luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */
+/* form: 2 halo flag, 1 serial, 0 events, -1 = GH_SHARD_STEP_FORM or the default (2).  The forms differ only in how a rank orders its own
+ * exchange and kernel; ranks of one job may use different forms. */
+GH_API int gh_comm_set_step_form(gh_comm_t comm, int form);
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream);

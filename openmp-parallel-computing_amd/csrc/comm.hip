@@ -109,12 +109,18 @@ struct Comm {
     uint32_t *started_sig = nullptr;     // `started` in signal memory (hipMallocSignalMemory) where the runtime has it: hipStreamWaitValue32 can poll it
     uint32_t *timeouts_host = nullptr, *timeouts_dev = nullptr;
     uint32_t epoch = 0;
+    int step_form = -1;                  // gh_comm_set_step_form: -1 = GH_SHARD_STEP_FORM / the default
 };
 
 __global__ void k_set_halo_flag(uint32_t *flag, uint32_t epoch)
 {
     GH_HALO_TRACE_AT(flag, 2);
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_store_u32(uint32_t *p, uint32_t v)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // in front of the exchange on the side stream: until the shard kernel of this step has begun on the caller's stream (gh_common.h)
@@ -174,8 +180,9 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
         GH_HIP_TRY(hipMalloc((void **)&c->flag_dev, 256));
         GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
-        int can_wait = 0;
-        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, 0) == hipSuccess && can_wait &&
+        int can_wait = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can_wait &&
             hipExtMallocWithFlags((void **)&c->started_sig, 8, hipMallocSignalMemory) == hipSuccess) {
             if (hipMemset(c->started_sig, 0, 8) != hipSuccess) { (void)hipFree(c->started_sig); c->started_sig = nullptr; }
         } else {
@@ -202,6 +209,17 @@ int gh_comm_set_loopback(gh_comm_t comm, int on)
 {
     GH_REQUIRE(comm, "null communicator");
     static_cast<Comm *>(comm)->loopback = on != 0;
+    return GH_OK;
+}
+
+// Which form the single-frame sharded steps of this communicator take: 2 halo flag, 1 serial, 0 events (see sharded_step below);
+// -1 = back to GH_SHARD_STEP_FORM / the default.  Every rank must choose alike only in the sense that each rank's own steps are
+// self-contained: the forms differ in how a rank orders ITS exchange and ITS kernel, the ncclSend / ncclRecv pairs are the same.
+int gh_comm_set_step_form(gh_comm_t comm, int form)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(form >= -1 && form <= 2, "form must be -1, 0, 1 or 2");
+    static_cast<Comm *>(comm)->step_form = form;
     return GH_OK;
 }
 
@@ -320,7 +338,7 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     //    is not hidden: 41 / 61 / 110 us (round 2's default).
     //  0 overlapped with events: exchange on the side stream || interior rows, then two one-row launches behind an event -- pays two
     //    cross-queue event hand-overs and two extra launches: 58 / 65 / 116 us.
-    int form = GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
+    int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
     if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
         GhHaloWait probe{};
         probe.pad = 1;
@@ -360,7 +378,14 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         }
         // Later work on s is ordered behind this launch, which cannot finish before the flag is set, i.e. before the exchange has
         // completed: the caller may overwrite the shard's rows right after the step, as with the other forms.
-        return launch_wait(up < 0, down < 0, hw);
+        const int rc = launch_wait(up < 0, down < 0, hw);
+        if (rc != GH_OK) {
+            // the shard kernel was not launched: nobody will ever store `started`, and the side stream (a command-processor wait has no
+            // time-out) would sit in front of the exchange for good -- release it from the caller's stream
+            k_store_u32<<<1, 64, 0, s>>>(hw.started, hw.epoch);
+            (void)hipGetLastError();
+        }
+        return rc;
     }
     // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
     GH_HIP_TRY(hipEventRecord(c->ready, s));

@@ -133,6 +133,10 @@ class NativeHaloComm:
         """One-GPU rehearsal: both neighbours of the sharded steps are this rank (see gh_comm_set_loopback)."""
         self.abi.check(self.lib.gh_comm_set_loopback(self.handle, int(on)), "gh_comm_set_loopback")
 
+    def set_step_form(self, form: int):
+        """Form of the single-frame sharded steps: 2 halo flag (default), 1 serial, 0 events, -1 = environment / default."""
+        self.abi.check(self.lib.gh_comm_set_step_form(self.handle, int(form)), "gh_comm_set_step_form")
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gh_comm_destroy(self.handle)

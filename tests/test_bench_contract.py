@@ -157,6 +157,7 @@ def test_loopback_rehearsal_drives_the_native_step_forms():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
     assert out["exchange_fallback"] is False and out["exchange_issuer"].startswith("libgrayhip")
+    assert out["shard_step_form"].startswith("halo flag")
     assert out["step_forms"]["single_frame"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.01)
     assert out["step_forms"]["pipelined"]["exchanges_per_step"] <= 0.35            # four frames per exchange (+ the cold start)
     assert out["halo_flag_timeouts"] == 0

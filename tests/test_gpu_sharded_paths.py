@@ -169,6 +169,39 @@ def test_unsharded_multipass_runner_equals_the_reference_pipeline(pkg, oracle, n
     assert np.array_equal(edge.cpu().numpy(), want_edge) and np.array_equal(buf[1:h + 1].cpu().numpy(), want_img)
 
 
+def test_step_form_is_selectable_per_communicator(pkg, oracle, native_comm, torch_mod):
+    """gh_comm_set_step_form: the form of the single-frame steps without touching the environment (bench.py falls back from the
+    halo-flag form to the serial one this way); all three give the same pixels, the counter sees one exchange per step."""
+    t = torch_mod
+    w, h = 2048, 70
+    img = oracle.frame_rand(w, h, 3, seed=77)
+    want = oracle.sobel(oracle.gray_to_plane(_replicate_padded(img), 0))[1:-1].copy()
+    want[:, 0] = 0
+    want[:, -1] = 0
+    native_comm.set_loopback(True)
+    try:
+        buf = t.full((h + 2, w, 3), 0x99, dtype=t.uint8, device="cuda")
+        buf[1:h + 1] = dev(t, img)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_step(buf, edge, h, 0)
+        for form in (1, 0, 2, -1):
+            native_comm.set_step_form(form)
+            edge.zero_()
+            buf[0] = 0x11
+            buf[h + 1] = 0x22
+            n0 = native_comm.exchange_count()
+            step()
+            step()
+            t.cuda.synchronize()
+            assert native_comm.exchange_count() - n0 == 2
+            assert np.array_equal(edge.cpu().numpy(), want), form
+        with pytest.raises(pkg.GrayHipError):
+            native_comm.set_step_form(3)
+    finally:
+        native_comm.set_step_form(-1)
+        native_comm.set_loopback(False)
+
+
 # ---- old/parallel_to_grayscale.c:12,36-37: min / max across ranks -----------------------------------------------------------
 
 def test_minmax_allreduce_native(pkg, oracle, native_comm, torch_mod):
