@@ -275,7 +275,14 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
         if (lane == 0 && nl < 3) ql = nl == 0 ? 0u : ql & (~0u << (8 * (4 - nl)));
         if (lane == 63 && nr < 3) qr = nr <= 0 ? 0u : qr & (~0u >> (8 * (4 - nr)));
         const int yin = y0 - 1 + i;
-        if (yin < ylo || yin > yhi) { q = make_uint4(0, 0, 0, 0); ql = 0; qr = 0; }
+        // rows beyond the frame (the zero border): only a band's first and last input row can be one -- in the regular form two statically
+        // known steps -- and the (wave-uniform) test is a scalar branch, not six selects on every row
+        if (!REG || (KIND == 3 && j == 0) || (KIND == 4 && j == CHK - 1)) {
+            if (__builtin_expect(yin < ylo || yin > yhi, 0)) {
+                asm volatile("" ::: "memory");
+                q = make_uint4(0, 0, 0, 0); ql = 0; qr = 0;
+            }
+        }
         // p[-3..18] as floats; pair layout G[m] = (p[m-3], p[m+5]), m = 0..13
         const uint32_t wv[6] = {ql, q.x, q.y, q.z, q.w, qr};                   // wv[0] bytes = p[-4..-1]
         f32x2 G[14];
