@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity stress of the LDS-DMA kernels under memory-latency noise (GPU box).
+"""Randomised parity stress of the LDS-DMA kernels and of the sharded step's halo-flag handshake under memory-latency noise (GPU box).
 
 The ring kernels do their own s_waitcnt vmcnt accounting; a wrong count would show up as rare, timing-dependent corrupt
 rows.  tests/test_isa_vmcnt.py checks the counts on the generated code; this is the dynamic counterpart: it loops for N
@@ -19,7 +19,9 @@ KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": 
              {"GH_FUSED_DMA_ORDER": "0", "GH_SOBEL_ORDER": "0"}, {"GH_FUSED_DMA_ORDER": "4", "GH_SOBEL_ORDER": "4"},
              {"GH_FUSED_DMA_ORDER": "2008", "GH_SOBEL_ORDER": "2006"}, {"GH_FUSED_DMA_PAD_KB": "0"},
              {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"},
-             {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_CONV_R": "16"}, {"GH_CONV_ORDER": "0"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"}]
+             {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_CONV_R": "16"}, {"GH_CONV_ORDER": "0"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"},
+             {"GH_SOBEL_NS": "4"}, {"GH_SOBEL_NS": "4", "GH_SOBEL_NS4_D": "2", "GH_SOBEL_R": "16"}, {"GH_SOBEL_NS": "4", "GH_SOBEL_NS4_CORE": "0", "GH_SOBEL_NS4_D": "6"},
+             {"GH_CONV_R": "22"}, {"GH_SHARD_STEP_FORM": "1"}, {"GH_SHARD_STEP_FORM": "0"}, {"GH_HALO_MEMOPS": "0"}, {"GH_HALO_MEMOPS": "3"}]
 
 
 def run(secs: float, seed: int, verbose: bool = True):
@@ -36,6 +38,15 @@ def run(secs: float, seed: int, verbose: bool = True):
     noise_a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     noise_b = torch.empty_like(noise_a)
     side = torch.cuda.Stream()
+    # round 3: the single-frame sharded steps in RCCL loopback (both neighbours are the shard itself) are in the draw -- the halo-flag
+    # form's two polled dwords, its upward-walking first band and the wait in front of the halo row meet the same latency noise
+    comm = None
+    try:
+        comm = pkg.sharding.NativeHaloComm(0, 1)
+        comm.set_loopback(True)
+    except Exception as exc:                                  # (no RCCL on this box: the kernels alone)
+        if verbose:
+            print("stress: no loopback communicator:", exc, flush=True)
     allk = {k for d in KNOB_SETS for k in d} | {"GH_FUSED_UNALIGNED_MIN_PX", "GH_SOBEL_UNALIGNED_MIN_PX"}
     saved = {k: os.environ.get(k) for k in allk}
     t_end, n, bad = time.time() + secs, 0, 0
@@ -68,7 +79,35 @@ def run(secs: float, seed: int, verbose: bool = True):
             if ch == 3 and rnd.randint(3) == 0:                  # the 3x3 convolution's ring kernel shares the DMA machinery
                 kern, norm = [([1, 2, 1, 2, 4, 2, 1, 2, 1], 16), ([0, -1, 0, -1, 5, -1, 0, -1, 0], 1), ([1] * 9, 9), ([-1, -2, -1, 0, 0, 0, 1, 2, 1], 2)][rnd.randint(4)]
                 conv = (api.conv3x3(d, kern, norm), O.conv3x3(img, kern, norm))
+            shard = None
+            if comm is not None and h >= 3 and rnd.randint(3) == 0:
+                padded = np.concatenate([luma[:1], luma, luma[-1:]], axis=0)           # loopback: the halo rows are the shard's own edge rows
+                want_s = O.sobel(padded)[1:-1].copy()
+                want_s[:, 0] = 0
+                want_s[:, -1] = 0
+                buf = torch.full((h + 2, w, ch), 0xA5, dtype=torch.uint8, device="cuda")
+                buf[1:h + 1] = d
+                e1 = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+                lbuf = torch.full((h + 2, w), 0x5A, dtype=torch.uint8, device="cuda")
+                lbuf[1:h + 1] = torch.from_numpy(luma).cuda()
+                e2 = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+                f1, f2 = comm.bind_fused_step(buf, e1, h, mode), comm.bind_sobel_step(lbuf, e2, h)
+                for _ in range(int(rnd.randint(1, 4))):                                # back-to-back steps: step k+1's exchange vs step k's reads
+                    f1()
+                    f2()
+                shard = (e1, e2, want_s)
             torch.cuda.synchronize()
+            if shard is not None:
+                for e_ in shard[:2]:
+                    n += 1
+                    if not np.array_equal(e_.cpu().numpy(), shard[2]):
+                        bad += 1
+                        if verbose:
+                            print("MISMATCH sharded step", w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
+                if pkg.abi.load().gh_comm_halo_timeouts(comm.handle):
+                    bad += 1
+                    if verbose:
+                        print("halo-flag wait timed out", flush=True)
             for o in outs:
                 n += 1
                 if not np.array_equal(o.cpu().numpy(), want):
@@ -82,6 +121,8 @@ def run(secs: float, seed: int, verbose: bool = True):
                     if verbose:
                         print("MISMATCH conv", w, h, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
     finally:
+        if comm is not None:
+            comm.close()
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
