@@ -330,14 +330,16 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
                             gh_comm_halo_timeouts(c));
     uint8_t *send_up = buf + row_bytes, *recv_up = buf, *send_down = buf + (size_t)rows * row_bytes, *recv_down = buf + (size_t)(rows + 1) * row_bytes;
-    // Three forms (GH_SHARD_STEP_FORM; loopback rehearsal, 16384-wide shards of 2048 / 4096 / 8192 rows, us per step):
+    // Three forms (GH_SHARD_STEP_FORM / gh_comm_set_step_form; loopback rehearsal, 16384-wide shards of 2048 / 4096 / 8192 rows, us per step;
+    // tools/sweep.py shard_forms):
     //  2 halo flag (default where the shard runs an LDS-DMA ring kernel): the exchange on the side stream BESIDE one launch over the whole
-    //    shard; only the first / last band's workgroups wait -- inside the kernel -- for a flag that a one-wave kernel behind the ncclRecv
-    //    sets.  No event on the caller's stream, no extra launches: the step costs max(kernel, exchange + one band).
+    //    shard; the two sides meet through two polled dwords (`started`, `flag`: gh_common.h), only the first / last band's workgroups wait --
+    //    inside the kernel, in front of their halo row's request.  No event, no extra launch on the caller's stream: 33.7 / 52.7 / 97.4
+    //    (the launch alone: 29.3 / 50.4 / 96.0).
     //  1 serial: the exchange on the caller's stream in front of ONE launch -- no side stream, no events; the exchange (one row, ~11 us)
-    //    is not hidden: 41 / 61 / 110 us (round 2's default).
+    //    is not hidden: 40.0 / 62.7 / 110.7 (round 2's default).
     //  0 overlapped with events: exchange on the side stream || interior rows, then two one-row launches behind an event -- pays two
-    //    cross-queue event hand-overs and two extra launches: 58 / 65 / 116 us.
+    //    cross-queue event hand-overs (~20 us each on this runtime) and two extra launches: 58.2 / 66.9 / 116.7.
     int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
     if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
         GhHaloWait probe{};

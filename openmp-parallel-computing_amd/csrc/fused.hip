@@ -589,7 +589,8 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
         if (dma_ok) {
             int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
             if (rd <= 0) {
-                rd = stream_core::fused_band_rows(groups_x, rows, (long long)width * channels, gh_num_cu(), GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0);
+                rd = stream_core::fused_band_rows(groups_x, rows, (long long)width * channels, gh_num_cu(), GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0,
+                                                  hw != nullptr && GH_TUNE_INT("GH_SHARD_BAND_RULE", 1) != 0);
             }
             const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
             const int R_ = rd;

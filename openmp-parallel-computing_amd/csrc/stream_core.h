@@ -577,9 +577,15 @@ inline bool shifted_band_overflows(long long groups_x, int rows, int R, int /*wg
 // 384 = 1.5 per CU, 0.0887 vs 0.0813 with 32-row and 0.0771 with 16-row bands; 10240^2: 480, 0.0887 vs 0.0840 with 32) -- "balance" =
 // workgroups / (CUs x rounds needed); band starts that alias onto a few channel phases are demoted (prefer_short_bands: 10240 x 16384
 // 0.1377 ms with 64-row bands, 0.1298 with 32; 12288 x 8192 0.0813 with 32, 0.0771 with 16).
-inline int fused_band_rows(int groups_x, int rows, long long pitch_bytes, int num_cu, bool alias_rule)
+// beside_exchange: the launch is the shard kernel of a sharded step in its halo-flag form (an RCCL exchange runs beside it, its edge
+// bands wait for their halo row).  There 32-row bands that give every CU exactly one workgroup beat the 16-row bands the kernel alone
+// prefers: 16384 x 2048 (the shard of eight GPUs) 32.6-32.9 us per step against 39.2 (tools/sweep.py shard_step_heights) -- an edge band of
+// 32 rows reaches its halo row when the kernel is nearly over, and 256 fat workgroups leave the exchange's kernel more room than 512
+// thin ones -- while the kernel alone measures the same either way (29.3 vs 29.8 us).
+inline int fused_band_rows(int groups_x, int rows, long long pitch_bytes, int num_cu, bool alias_rule, bool beside_exchange = false)
 {
     const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
+    if (beside_exchange && nb64 < num_cu && nb32 >= num_cu && nb32 < 2ll * num_cu && wg_balance(nb32, num_cu) >= 0.97) return 32;
     int rd = (nb64 >= 2ll * num_cu || (nb64 >= num_cu && wg_balance(nb64, num_cu) >= 0.97)) ? 64
              : ((nb32 >= 2ll * num_cu && wg_balance(nb32, num_cu) >= 0.9) ? 32 : 16);
     if (alias_rule) {

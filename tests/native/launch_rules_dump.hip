@@ -26,6 +26,7 @@ int main()
             const int gx = (f[0] + 4095) / 4096;
             printf("rows_fused %d %d %d %d\n", cus, f[0], f[1], stream_core::fused_band_rows(gx, f[1], 3ll * f[0], cus, true));
             printf("rows_sobel %d %d %d %d\n", cus, f[0], f[1], stream_core::sobel_band_rows(gx, f[1], f[0], cus, true, true, true));
+            printf("rows_fused_shard %d %d %d %d\n", cus, f[0], f[1], stream_core::fused_band_rows(gx, f[1], 3ll * f[0], cus, true, true));
         }
     return 0;
 }

@@ -169,6 +169,36 @@ def test_unsharded_multipass_runner_equals_the_reference_pipeline(pkg, oracle, n
     assert np.array_equal(edge.cpu().numpy(), want_edge) and np.array_equal(buf[1:h + 1].cpu().numpy(), want_img)
 
 
+def test_shard_kernel_beside_an_exchange_takes_fat_bands(pkg, oracle, native_comm, torch_mod):
+    """The shard of eight GPUs (16384 x 2048): alone the fused kernel runs 16-row regular bands; as the shard kernel of a halo-flag step
+    it runs 32-row bands, one workgroup per CU (stream_core::fused_band_rows, beside_exchange) -- 33.5 against 39.2 us per step in the
+    loopback rehearsal.  Same pixels either way."""
+    t = torch_mod
+    w, h = 16384, 2048
+    img = oracle.frame_rand(w, h, 3, seed=5)
+    buf = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+    buf[1:h + 1] = dev(t, img)
+    alone = pkg.hostapi.gray_sobel_fused_rows(buf, t.empty((h, w), dtype=t.uint8, device="cuda"), h, 0, False, False)
+    assert pkg.hostapi.last_kernel() == "k_fused_dma regular R=16"
+    native_comm.set_loopback(True)
+    try:
+        buf[0] = buf[1]
+        buf[h + 1] = buf[h]
+        want = pkg.hostapi.gray_sobel_fused_rows(buf, t.empty((h, w), dtype=t.uint8, device="cuda"), h, 0, False, False).clone()
+        buf[0] = 0x13
+        buf[h + 1] = 0x31
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        native_comm.bind_fused_step(buf, edge, h, 0)()
+        t.cuda.synchronize()
+        assert pkg.hostapi.last_kernel() == "k_fused_dma D=3"
+        assert t.equal(edge, want)
+        pad = np.concatenate([img[:1], img[:40]], axis=0)                       # and against the oracle on the first rows
+        assert np.array_equal(edge[:38].cpu().numpy()[:, 1:-1], oracle.sobel(oracle.gray_to_plane(pad, 0))[1:39, 1:-1])
+    finally:
+        native_comm.set_loopback(False)
+    del alone
+
+
 def test_step_form_is_selectable_per_communicator(pkg, oracle, native_comm, torch_mod):
     """gh_comm_set_step_form: the form of the single-frame steps without touching the environment (bench.py falls back from the
     halo-flag form to the serial one this way); all three give the same pixels, the counter sees one exchange per step."""

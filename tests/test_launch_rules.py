@@ -67,8 +67,10 @@ def test_helpers_equal_their_restatement(dump):
     assert seen >= {"phases", "prefer", "balance", "overflow", "rows_fused", "rows_sobel"}
 
 
-def fused_rows(gx, rows, pitch, cu):
+def fused_rows(gx, rows, pitch, cu, beside_exchange=False):
     nb64, nb32 = gx * -(-rows // 64), gx * -(-rows // 32)
+    if beside_exchange and nb64 < cu and cu <= nb32 < 2 * cu and balance(nb32, cu) >= 0.97:
+        return 32
     rd = 64 if (nb64 >= 2 * cu or (nb64 >= cu and balance(nb64, cu) >= 0.97)) else (32 if (nb32 >= 2 * cu and balance(nb32, cu) >= 0.9) else 16)
     if rd == 64 and prefer_short(pitch, 64, 32) and nb32 >= cu:
         rd = 32
@@ -93,12 +95,16 @@ def test_band_heights_follow_the_device_cu_count(dump):
     """The launchers size their plans for the CU count the device reports (gh_init), not for a constant: the rules are pure functions
     of (geometry, CUs).  Checked against a restatement for 256 CUs (MI355X, SPX), 32 (a CPX partition) and 304; and the point of it:
     a partition with an eighth of the CUs gives a frame with an eighth of the rows the plan the whole chip gives the whole frame."""
-    got = {(r[0], int(r[1]), int(r[2]), int(r[3])): int(r[4]) for r in dump if r[0] in ("rows_fused", "rows_sobel")}
-    assert len(got) >= 60
+    got = {(r[0], int(r[1]), int(r[2]), int(r[3])): int(r[4]) for r in dump if r[0] in ("rows_fused", "rows_sobel", "rows_fused_shard")}
+    assert len(got) >= 90
     for (kind, cu, w, h), val in got.items():
         gx = -(-w // 4096)
-        want = fused_rows(gx, h, 3 * w, cu) if kind == "rows_fused" else sobel_rows(gx, h, w, cu)
+        want = sobel_rows(gx, h, w, cu) if kind == "rows_sobel" else fused_rows(gx, h, 3 * w, cu, kind == "rows_fused_shard")
         assert val == want, (kind, cu, w, h, val, want)
+    # the shard kernel of a sharded step (an exchange runs beside it): 32-row bands where they give every CU exactly one workgroup
+    assert got[("rows_fused_shard", 256, 16384, 2048)] == 32 and got[("rows_fused", 256, 16384, 2048)] == 16
+    assert got[("rows_fused_shard", 256, 16384, 4096)] == got[("rows_fused", 256, 16384, 4096)] == 64
+    assert got[("rows_fused_shard", 256, 16384, 8192)] == 64 and got[("rows_fused_shard", 32, 16384, 512)] == got[("rows_fused_shard", 256, 16384, 4096)]
     assert got[("rows_fused", 256, 16384, 16384)] == 64 and got[("rows_fused", 256, 16384, 2048)] == 16        # the headline and the 8-GPU shard
     assert got[("rows_fused", 32, 16384, 2048)] == got[("rows_fused", 256, 16384, 16384)]                      # 1/8 of the CUs, 1/8 of the rows
     assert got[("rows_sobel", 32, 16384, 2048)] == got[("rows_sobel", 256, 16384, 16384)] == 64
