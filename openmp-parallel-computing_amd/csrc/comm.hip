@@ -162,6 +162,7 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
     Comm *c = new Comm;
     c->rank = rank;
     c->world = world;
+    c->epoch = (uint32_t)GH_TUNE_INT("GH_HALO_EPOCH_START", 0);      // (tests start near the wrap guard of the halo-flag form)
     NcclId nid;
     memcpy(nid.internal, id, kIdBytes);
     const int r = g_rccl.CommInitRank(&c->nccl, world, nid, rank);
@@ -359,6 +360,15 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         // 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- hence 2.
         const int memops = GH_TUNE_INT("GH_HALO_MEMOPS", 2);
         const bool sig_wait = (memops & 2) && c->started_sig;
+        if (c->epoch >= 0x7ffffff0u) {
+            // the epochs are compared as 32-bit numbers (the command processor's wait: unsigned): long before they could wrap -- 2^31 steps,
+            // about a day of back-to-back 40 us steps -- both streams are drained once and the words start again from zero
+            GH_HIP_TRY(hipStreamSynchronize(s));
+            GH_HIP_TRY(hipStreamSynchronize(c->side));
+            GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
+            if (c->started_sig) GH_HIP_TRY(hipMemset(c->started_sig, 0, 8));
+            c->epoch = 0;
+        }
         GhHaloWait hw{};
         hw.flag = c->flag_dev;
         hw.started = sig_wait ? c->started_sig : c->flag_dev + 32;

@@ -199,6 +199,41 @@ def test_shard_kernel_beside_an_exchange_takes_fat_bands(pkg, oracle, native_com
     del alone
 
 
+def test_halo_flag_epochs_restart_before_they_could_wrap(pkg, oracle, torch_mod, monkeypatch):
+    """The handshake compares 32-bit epochs; at 0x7ffffff0 the step drains both streams once and starts again from zero.  A
+    communicator that begins 12 steps before that point runs 40 steps across it: every result right, no wait timed out."""
+    t = torch_mod
+    monkeypatch.setenv("GH_HALO_EPOCH_START", str(0x7ffffff0 - 12))
+    comm = pkg.sharding.NativeHaloComm(0, 1)
+    monkeypatch.delenv("GH_HALO_EPOCH_START")
+    try:
+        comm.set_loopback(True)
+        w, h = 2048, 70
+        imgs = [oracle.frame_rand(w, h, 3, seed=900 + i) for i in range(2)]
+        wants = []
+        for img in imgs:
+            e = oracle.sobel(oracle.gray_to_plane(_replicate_padded(img), 0))[1:-1].copy()
+            e[:, 0] = 0
+            e[:, -1] = 0
+            wants.append(e)
+        buf = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = comm.bind_fused_step(buf, edge, h, 0)
+        for k in range(40):
+            buf[1:h + 1] = dev(t, imgs[k & 1])          # a new frame in front of every step (enqueued on the same stream)
+            buf[0] = 0x5A
+            buf[h + 1] = 0xA5
+            step()
+            if k % 7 == 0 or k in (11, 12, 13):
+                t.cuda.synchronize()
+                assert np.array_equal(edge.cpu().numpy(), wants[k & 1]), k
+        t.cuda.synchronize()
+        assert np.array_equal(edge.cpu().numpy(), wants[39 & 1])
+        assert pkg.abi.load().gh_comm_halo_timeouts(comm.handle) == 0 and comm.exchange_count() == 40
+    finally:
+        comm.close()
+
+
 def test_step_form_is_selectable_per_communicator(pkg, oracle, native_comm, torch_mod):
     """gh_comm_set_step_form: the form of the single-frame steps without touching the environment (bench.py falls back from the
     halo-flag form to the serial one this way); all three give the same pixels, the counter sees one exchange per step."""
