@@ -221,7 +221,9 @@ def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
                                     "GH_FUSED_DMA_R2": "16"}, {"GH_FUSED_DMA": "0", "GH_FUSED_VARIANT": "1"},
                                    {"GH_FUSED_DMA_R": "24", "GH_FUSED_DMA_ORDER": "2"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "1234"},
                                    {"GH_FUSED_DMA_R": "40", "GH_FUSED_DMA_ORDER": "1010"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "304"},
-                                   {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "0"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "36"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "8"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "2008"}, {"GH_FUSED_DMA_ORDER": "2006"}])
+                                   {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "0"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "36"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "8"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "2008"}, {"GH_FUSED_DMA_ORDER": "2006"},
+                                   {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "34"}, {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "64"},
+                                   {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "22", "GH_FUSED_DMA_PAD_KB": "30"}])
 def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     """Every tuning variant of the fused kernel (register-staged, LDS-DMA ring depths, band plans) is bit-exact too.
     tests/conftest.py sets GH_TUNE_DYNAMIC so that the library re-reads the knobs on every launch."""
