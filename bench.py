@@ -25,9 +25,10 @@ contract's bracket (barrier + synchronize on both sides, MAX over ranks):
                   stream beside ONE launch over the shard whose first / last band wait, inside the kernel, for a flag set behind
                   the ncclRecv (csrc/comm.hip; GH_SHARD_STEP_FORM=1: exchange, then launch);
     end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory (SURVEY 8(d));
-    pipelined     a different experiment, reported beside it: a STREAM of frames in a ring of eight buffers, the halo rows of the
-                  next four frames travel in ONE exchange while the current four run, one launch per step (--halo-batch 0: one
-                  exchange per frame, two frames ahead).
+    stream_of_frames  the single-frame step on a ring of eight DIFFERENT frames (no frame seen twice in a row: nothing cached);
+    pipelined     a different experiment, reported beside them: the same stream with the halo rows of the next four frames
+                  prefetched in ONE exchange while the current four run, one launch per step (--halo-batch 0: one exchange per
+                  frame, two frames ahead).
 The line also says who issued the exchange (`exchange_fallback` true = torch.distributed P2P instead of libgrayhip's own RCCL
 communicator), fails (rc 4) when that communicator did not meet all N ranks, and carries a per-rank breakdown -- shard kernel alone,
 exchange alone, the whole step -- so that one run explains the shape of the scaling curve.
@@ -762,6 +763,7 @@ def main() -> int:
 
         pipelined_impl, edge_of = torch_step, (lambda k: runners[k % NBUF].edge)
         single_impl, single_edge = (lambda k: torch_step(0)), runners[0].edge
+        stream_impl = torch_step          # a stream of DIFFERENT frames, each step the whole single-frame step on the next one
         if native is not None:
             # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
             AHEAD = 2
@@ -772,6 +774,8 @@ def main() -> int:
                     native_step = pstep
                     sstep = native.bind_fused_step(halo_bufs[0], edge_native, rows, mode)
                     native_single = lambda k: sstep()
+                    ring_steps = [native.bind_fused_step(hb, edge_native, rows, mode) for hb in halo_bufs]
+                    native_stream = lambda k: ring_steps[k % NBUF]()
                     # batched form: the halos of BATCH future frames in one group, a step = one launch (checked below like the other)
                     bstep = native.bind_fused_step_batched(halo_bufs, edge_native, rows, mode, BATCH) if args.halo_batch else None
                 else:
@@ -788,6 +792,11 @@ def main() -> int:
                     def native_single(k):
                         grays[0]()
                         sstep()
+                    ring_steps = [native.bind_sobel_step(hb, edge_native, rows) for hb in halo_bufs]
+
+                    def native_stream(k):
+                        grays[k % NBUF]()
+                        ring_steps[k % NBUF]()
                 # every frame of the ring through both paths: the C++ path must reproduce torch.distributed bit for bit
                 same = True
                 for k in range(NBUF):
@@ -833,6 +842,7 @@ def main() -> int:
                             f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed")
                 pipelined_impl, edge_of = native_step, (lambda k: edge_native)
                 single_impl, single_edge = native_single, edge_native
+                stream_impl = native_stream
                 if fused and bstep is not None and all_ranks_agree(same_b or rehearsal_loopback):
                     exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv groups on a side stream, issued from C++; "
                                 f"pipelined form: the halo rows of the next {BATCH} frames travel in ONE group while the current {BATCH} are "
@@ -956,7 +966,10 @@ def main() -> int:
             single_impl(k)
         k_e2e = max(1, min(args.steps, 20))
         forms["end_to_end_h2d"], _ = run_form(e2e_impl, k_e2e, "end_to_end_h2d")
-        # (c) a stream of frames, software-pipelined: another experiment (throughput of a stream, not the latency of one frame)
+        # (c) a stream of DIFFERENT frames (ring of eight), every step the whole single-frame step -- its own exchange and its own launch --
+        # on the next frame: what `value` becomes when no frame is seen twice (nothing of it can sit in the 256 MB Infinity Cache)
+        forms["stream_of_frames"], _ = run_form(stream_impl, args.steps, "stream_of_frames")
+        # (d) the same stream software-pipelined: the halo rows of later frames prefetched in groups -- fewer, larger exchanges
         xc1 = native.exchange_count() if native is not None else 0
         forms["pipelined"], _ = run_form(pipelined_impl, args.steps, "pipelined")
         if native is not None:
@@ -1010,7 +1023,11 @@ def main() -> int:
                     "traffic_source": "not recorded for shards (the 1-GPU line carries the PMC figure of the same kernel)"}
         out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
                     "step_single_frame_ms": forms["single_frame"]["ms_per_step"], "step_pipelined_ms": forms["pipelined"]["ms_per_step"],
-                    "step_end_to_end_ms": forms["end_to_end_h2d"]["ms_per_step"], "step_forms": forms,
+                    "step_end_to_end_ms": forms["end_to_end_h2d"]["ms_per_step"], "step_stream_of_frames_ms": forms["stream_of_frames"]["ms_per_step"],
+                    "step_forms": forms,
+                    "working_set_note": (f"per GPU the step touches {px_rank * 4 / 1e6:.0f} MB (shard in, edge plane out); the single-frame form re-reads ONE shard, of which a "
+                                         "256 MB Infinity Cache can keep a part once that is small enough (N >= 4 for this frame) -- stream_of_frames is the same step "
+                                         "on eight different frames, where nothing is seen twice"),
                     "repeats": {"ms_per_step": [round(v, 4) for v in rep_ms], "min": round(min(rep_ms), 4),
                                 "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4), "max": round(max(rep_ms), 4),
                                 "note": "the K-step bracket of the single-frame form run again back to back; value / ms_per_step are the first entry"},

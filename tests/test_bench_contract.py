@@ -131,7 +131,7 @@ def test_plain_command_runs_two_ranks_in_rehearsal():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks"] == 2
-    for k in ("step_single_frame_ms", "step_pipelined_ms", "step_end_to_end_ms"):
+    for k in ("step_single_frame_ms", "step_pipelined_ms", "step_end_to_end_ms", "step_stream_of_frames_ms"):
         assert out[k] > 0
     # the headline of N > 1 is the configuration BASELINE configs[3] describes: ONE frame split N ways
     assert out["ms_per_step"] == out["step_single_frame_ms"] == out["step_forms"]["single_frame"]["ms_per_step"]
