@@ -26,9 +26,9 @@ contract's bracket (barrier + synchronize on both sides, MAX over ranks):
                   the ncclRecv (csrc/comm.hip; GH_SHARD_STEP_FORM=1: exchange, then launch);
     end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory (SURVEY 8(d));
     stream_of_frames  the single-frame step on a ring of eight DIFFERENT frames (no frame seen twice in a row: nothing cached);
-    pipelined     a different experiment, reported beside them: the same stream with the halo rows of the next four frames
-                  prefetched in ONE exchange while the current four run, one launch per step (--halo-batch 0: one exchange per
-                  frame, two frames ahead).
+    pipelined     a different experiment, reported beside them: the same stream, the halo rows of frame k+1 travelling beside the
+                  launch on frame k (gh_sharded_fused_stream_step_dev: the halo-flag handshake, no event between the streams);
+    pipelined_batched  round 2's form of it: the halo rows of the next four frames in ONE exchange, events (--halo-batch 0: not timed).
 The line also says who issued the exchange (`exchange_fallback` true = torch.distributed P2P instead of libgrayhip's own RCCL
 communicator), fails (rc 4) when that communicator did not meet all N ranks, and carries a per-rank breakdown -- shard kernel alone,
 exchange alone, the whole step -- so that one run explains the shape of the scaling curve.
@@ -764,13 +764,16 @@ def main() -> int:
         pipelined_impl, edge_of = torch_step, (lambda k: runners[k % NBUF].edge)
         single_impl, single_edge = (lambda k: torch_step(0)), runners[0].edge
         stream_impl = torch_step          # a stream of DIFFERENT frames, each step the whole single-frame step on the next one
+        batched_impl = None               # (native only) the same stream with the halo rows of four future frames per exchange
         if native is not None:
             # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
             AHEAD = 2
             edge_native = torch.empty((rows, W), dtype=torch.uint8, device=device)
             try:
                 if fused:
-                    pstep = native.bind_fused_step_pipelined(halo_bufs, edge_native, rows, mode, ahead=AHEAD)
+                    # stream of frames: the halo rows of frame k + 1 travel beside the launch on frame k, the two sides meeting through the
+                    # polled dwords of the halo-flag form (gh_sharded_fused_stream_step_dev)
+                    pstep = native.bind_fused_stream_step(halo_bufs, edge_native, rows, mode)
                     native_step = pstep
                     sstep = native.bind_fused_step(halo_bufs[0], edge_native, rows, mode)
                     native_single = lambda k: sstep()
@@ -839,17 +842,15 @@ def main() -> int:
                 same, same_b, exchange_note = False, False, f"native step failed on rank {rank}: {exc}"
             if all_ranks_agree(same or rehearsal_loopback):
                 exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
-                            f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed")
+                            + ("pipelined form: the halo rows of frame k+1 travel beside the launch on frame k, no event between the streams"
+                               if fused else f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed"))
                 pipelined_impl, edge_of = native_step, (lambda k: edge_native)
                 single_impl, single_edge = native_single, edge_native
                 stream_impl = native_stream
                 if fused and bstep is not None and all_ranks_agree(same_b or rehearsal_loopback):
-                    exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv groups on a side stream, issued from C++; "
-                                f"pipelined form: the halo rows of the next {BATCH} frames travel in ONE group while the current {BATCH} are "
-                                "processed, one launch per step")
-                    pipelined_impl = bstep        # (k runs on from 0 through run-in, warm-up and timed steps: a batch request every BATCH-th step)
+                    batched_impl = bstep          # (k runs on from 0 through run-in, warm-up and timed steps: a batch request every BATCH-th step)
                 elif fused and bstep is not None:
-                    exchange_note = exchange_note or "batched halo prefetch disagreed with torch.distributed on the first frames; one exchange per frame"
+                    exchange_note = exchange_note or "batched halo prefetch disagreed with torch.distributed on the first frames: not timed"
             else:
                 exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
                 native = None
@@ -969,7 +970,12 @@ def main() -> int:
         # (c) a stream of DIFFERENT frames (ring of eight), every step the whole single-frame step -- its own exchange and its own launch --
         # on the next frame: what `value` becomes when no frame is seen twice (nothing of it can sit in the 256 MB Infinity Cache)
         forms["stream_of_frames"], _ = run_form(stream_impl, args.steps, "stream_of_frames")
-        # (d) the same stream software-pipelined: the halo rows of later frames prefetched in groups -- fewer, larger exchanges
+        # (d) the same stream with the halo rows of four future frames per exchange (events; round 2's form): fewer, larger exchanges
+        if batched_impl is not None:
+            xc1 = native.exchange_count()
+            forms["pipelined_batched"], _ = run_form(batched_impl, args.steps, "pipelined_batched")
+            forms["pipelined_batched"]["exchanges_per_step"] = round((native.exchange_count() - xc1) / max(calls["pipelined_batched"], 1), 3)
+        # (e) the same stream software-pipelined: the halo rows of the next frame travel beside this frame's launch
         xc1 = native.exchange_count() if native is not None else 0
         forms["pipelined"], _ = run_form(pipelined_impl, args.steps, "pipelined")
         if native is not None:

@@ -232,6 +232,14 @@ GH_API int gh_sharded_fused_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_rgb_
                                                int width, int rows, int channels, int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *prefetch_luma_buf, uint8_t *edge,
                                                int width, int rows, gh_stream_t stream);
+/* The same stream of frames in the halo-flag way (the form to use on frames of 1024 columns and more): `cur` is filtered by one launch
+ * whose edge bands wait -- inside the kernel, in front of their halo row -- for the exchange the PREVIOUS call started when cur was its
+ * `next`; the halo rows of `next` (rows 1 / rows in place, enqueued on `stream`) travel on the side stream beside this launch.  No event
+ * and no stream-level wait: an exchange has a whole launch to complete before anything needs it.  cur not announced by the previous call
+ * (first call, another buffer): exchanged beside this launch, as in gh_sharded_fused_step_dev.  next may be NULL.  Narrow frames fall
+ * back to gh_sharded_fused_step_pipelined_dev. */
+GH_API int gh_sharded_fused_stream_step_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *next_rgb_buf, uint8_t *edge, int width, int rows,
+                                            int channels, int mode, gh_stream_t stream);
 /* Batched prefetch for the pipelined steps: the halo rows of n (1..16) frame buffers -- (rows + 2) rows of row_bytes each, rows
  * 1 / rows in place (enqueued on `stream`) -- are exchanged in ONE ncclGroup on the side stream, one event behind all of them.
  * The pipelined steps that later run on these buffers (prefetch = NULL) find their halos requested: the first waits for the

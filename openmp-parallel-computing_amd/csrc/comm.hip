@@ -108,7 +108,12 @@ struct Comm {
     uint32_t *flag_dev = nullptr;
     uint32_t *started_sig = nullptr;     // `started` in signal memory (hipMallocSignalMemory) where the runtime has it: hipStreamWaitValue32 can poll it
     uint32_t *timeouts_host = nullptr, *timeouts_dev = nullptr;
-    uint32_t epoch = 0;
+    uint32_t epoch = 0;                  // kernel launches that store `started`
+    uint32_t xepoch = 0;                 // halo exchanges that set `flag` behind them
+    // stream-of-frames step (gh_sharded_*_stream_step_dev): the buffer whose halo rows the previous call sent on their way, and the
+    // value `flag` takes once they have landed
+    const void *stream_buf = nullptr;
+    uint32_t stream_xepoch = 0;
     int step_form = -1;                  // gh_comm_set_step_form: -1 = GH_SHARD_STEP_FORM / the default
 };
 
@@ -162,7 +167,7 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
     Comm *c = new Comm;
     c->rank = rank;
     c->world = world;
-    c->epoch = (uint32_t)GH_TUNE_INT("GH_HALO_EPOCH_START", 0);      // (tests start near the wrap guard of the halo-flag form)
+    c->epoch = c->xepoch = (uint32_t)GH_TUNE_INT("GH_HALO_EPOCH_START", 0);      // (tests start near the wrap guard of the halo-flag form)
     NcclId nid;
     memcpy(nid.internal, id, kIdBytes);
     const int r = g_rccl.CommInitRank(&c->nccl, world, nid, rank);
@@ -320,6 +325,68 @@ int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev, gh_str
 // buf: (rows + 2) rows of `row_bytes`; rows 1..rows are the shard, rows 0 / rows+1 receive the neighbours' edge rows.
 // Two forms: serial (exchange, then one launch) and overlapped (exchange on the side stream || interior rows on the caller's
 // stream -> first and last row once the halo has landed).
+// ---- the halo-flag machinery shared by the single-frame step and the stream-of-frames step (gh_common.h) --------------------------
+// The epochs are compared as 32-bit numbers (the command processor's wait: unsigned): long before they could wrap -- 2^31 steps, about a
+// day of back-to-back 40 us steps -- both streams are drained once and the words start again from zero.
+static int halo_flag_guard(Comm *c, hipStream_t s)
+{
+    if (c->epoch < 0x7ffffff0u && c->xepoch < 0x7ffffff0u) return GH_OK;
+    GH_HIP_TRY(hipStreamSynchronize(s));
+    GH_HIP_TRY(hipStreamSynchronize(c->side));
+    GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
+    if (c->started_sig) GH_HIP_TRY(hipMemset(c->started_sig, 0, 8));
+    c->epoch = c->xepoch = 0;
+    c->stream_buf = nullptr;
+    return GH_OK;
+}
+
+// the launch's side of the handshake: a new `started` number; wait_epoch is filled in by whoever knows which exchange the launch needs
+static GhHaloWait halo_flag_launch_args(Comm *c)
+{
+    // GH_HALO_MEMOPS (bit 1: the wait, bit 0: the flag write) hands the two side-stream operations to the command processor
+    // (hipStreamWaitValue32 on signal memory / hipStreamWriteValue32) instead of one-wave kernels.  Measured (tools/sweep.py shard_memops,
+    // 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- hence 2.
+    const bool sig_wait = (GH_TUNE_INT("GH_HALO_MEMOPS", 2) & 2) && c->started_sig;
+    GhHaloWait hw{};
+    hw.flag = c->flag_dev;
+    hw.started = sig_wait ? c->started_sig : c->flag_dev + 32;
+    hw.timeouts = c->timeouts_dev;
+    hw.epoch = ++c->epoch;
+    hw.ticks = (unsigned long long)GH_TUNE_INT("GH_HALO_WAIT_MS", 10000) * 100000ull;       // 100 MHz constant clock
+    return hw;
+}
+
+// the side stream's part: behind `started` >= hw.epoch (the launch that carries hw has begun) the halo rows of `buf` are exchanged and
+// `flag` takes a new number, returned in *flag_number
+static int halo_flag_exchange(Comm *c, const GhHaloWait &hw, uint8_t *buf, size_t row_bytes, int rows, int up, int down, uint32_t *flag_number)
+{
+    if (hw.started == c->started_sig) {
+        GH_HIP_TRY(hipStreamWaitValue32(c->side, c->started_sig, hw.epoch, hipStreamWaitValueGte, 0xffffffffu));
+    } else {
+        k_wait_started<<<1, 64, 0, c->side>>>(hw.started, hw.epoch, hw.ticks, hw.timeouts, c->flag_dev);
+        GH_LAUNCH_CHECK();
+    }
+    if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes, row_bytes, c->side))
+        return rc;
+    const uint32_t f = ++c->xepoch;
+    if (GH_TUNE_INT("GH_HALO_MEMOPS", 2) & 1) {
+        GH_HIP_TRY(hipStreamWriteValue32(c->side, c->flag_dev, f, 0));
+    } else {
+        k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, f);
+        GH_LAUNCH_CHECK();
+    }
+    *flag_number = f;
+    return GH_OK;
+}
+
+// the shard kernel was not launched: nobody will ever store `started`, and the side stream (a command-processor wait has no time-out)
+// would sit in front of the exchange for good -- release it from the caller's stream
+static void halo_flag_release(hipStream_t s, const GhHaloWait &hw)
+{
+    k_store_u32<<<1, 64, 0, s>>>(hw.started, hw.epoch);
+    (void)hipGetLastError();
+}
+
 template <typename Launch, typename LaunchWait>
 static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */,
                         LaunchWait launch_wait /* (top_border, bot_border, const GhHaloWait &): the whole shard, edge bands wait for the flag */)
@@ -355,48 +422,13 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         // No event in either direction: the side stream polls `started` (stored by the shard kernel's first workgroup: everything
         // enqueued on s before this step has completed by then -- the rows to send are in place, the previous step has read its halo
         // rows), exchanges, and sets `flag`, which the shard kernel's edge bands poll.
-        // GH_HALO_MEMOPS (bit 1: the wait, bit 0: the flag write) hands the two side-stream operations to the command processor
-        // (hipStreamWaitValue32 on signal memory / hipStreamWriteValue32) instead of one-wave kernels.  Measured (tools/r3_shard_memops.sh,
-        // 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- hence 2.
-        const int memops = GH_TUNE_INT("GH_HALO_MEMOPS", 2);
-        const bool sig_wait = (memops & 2) && c->started_sig;
-        if (c->epoch >= 0x7ffffff0u) {
-            // the epochs are compared as 32-bit numbers (the command processor's wait: unsigned): long before they could wrap -- 2^31 steps,
-            // about a day of back-to-back 40 us steps -- both streams are drained once and the words start again from zero
-            GH_HIP_TRY(hipStreamSynchronize(s));
-            GH_HIP_TRY(hipStreamSynchronize(c->side));
-            GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
-            if (c->started_sig) GH_HIP_TRY(hipMemset(c->started_sig, 0, 8));
-            c->epoch = 0;
-        }
-        GhHaloWait hw{};
-        hw.flag = c->flag_dev;
-        hw.started = sig_wait ? c->started_sig : c->flag_dev + 32;
-        hw.timeouts = c->timeouts_dev;
-        hw.epoch = ++c->epoch;
-        hw.ticks = (unsigned long long)GH_TUNE_INT("GH_HALO_WAIT_MS", 10000) * 100000ull;       // 100 MHz constant clock
-        if (sig_wait) {
-            GH_HIP_TRY(hipStreamWaitValue32(c->side, c->started_sig, hw.epoch, hipStreamWaitValueGte, 0xffffffffu));
-        } else {
-            k_wait_started<<<1, 64, 0, c->side>>>(hw.started, hw.epoch, hw.ticks, hw.timeouts, c->flag_dev);
-            GH_LAUNCH_CHECK();
-        }
-        if (int rc = gh_halo_exchange_dev(c, up, send_up, recv_up, down, send_down, recv_down, row_bytes, c->side)) return rc;
-        if (memops & 1) {
-            GH_HIP_TRY(hipStreamWriteValue32(c->side, c->flag_dev, hw.epoch, 0));
-        } else {
-            k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, hw.epoch);
-            GH_LAUNCH_CHECK();
-        }
+        if (int rc = halo_flag_guard(c, s)) return rc;
+        GhHaloWait hw = halo_flag_launch_args(c);
+        if (int rc = halo_flag_exchange(c, hw, buf, row_bytes, rows, up, down, &hw.wait_epoch)) { halo_flag_release(s, hw); return rc; }
         // Later work on s is ordered behind this launch, which cannot finish before the flag is set, i.e. before the exchange has
         // completed: the caller may overwrite the shard's rows right after the step, as with the other forms.
         const int rc = launch_wait(up < 0, down < 0, hw);
-        if (rc != GH_OK) {
-            // the shard kernel was not launched: nobody will ever store `started`, and the side stream (a command-processor wait has no
-            // time-out) would sit in front of the exchange for good -- release it from the caller's stream
-            k_store_u32<<<1, 64, 0, s>>>(hw.started, hw.epoch);
-            (void)hipGetLastError();
-        }
+        if (rc != GH_OK) halo_flag_release(s, hw);
         return rc;
     }
     // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
@@ -530,6 +562,7 @@ int gh_sharded_prefetch_reset(gh_comm_t comm)
     GH_REQUIRE(comm, "null communicator");
     Comm *c = static_cast<Comm *>(comm);
     for (int i = 0; i < Comm::kEntries; ++i) c->pf_buf[i] = nullptr;
+    c->stream_buf = nullptr;
     return GH_OK;
 }
 
@@ -563,6 +596,51 @@ int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, u
     return sharded_step_pipelined(c, cur_luma_buf, prefetch_luma_buf, rb, rows, (hipStream_t)stream, [&](uint8_t *buf, int tb, int bb) {
         return gh_sobel_u8_rows_dev(buf + rb, edge, width, rows, tb, bb, stream);
     });
+}
+
+// Stream of frames in the halo-flag way: `cur` is filtered by ONE launch whose edge bands wait (in the kernel, in front of their halo row)
+// for the exchange that the PREVIOUS call sent on its way when `cur` was its `next`; the halo rows of `next` travel on the side stream
+// beside this launch, behind `started` -- no event, no stream-level wait.  By the time a launch needs its halo row the exchange has had a
+// whole launch to complete.  cur's halo rows not on their way (first call, another buffer): they are exchanged beside this launch, as in
+// the single-frame step.  Frames whose kernel form carries no flag wait: the event-based pipelined step.
+int gh_sharded_fused_stream_step_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *next_rgb_buf, uint8_t *edge, int width, int rows, int channels,
+                                     int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(cur_rgb_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rb = (size_t)width * channels;
+    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback) up = down = c->rank;
+    if (up < 0 && down < 0) return gh_gray_sobel_fused_rows_dev(cur_rgb_buf + rb, edge, width, rows, channels, mode, 1, 1, stream);
+    GhHaloWait probe{};
+    probe.pad = 1;
+    const int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
+    if (form != 2 || gh_fused_rows_halo_wait(cur_rgb_buf + rb, edge, width, rows, channels, mode, up < 0, down < 0, stream, &probe) != GH_OK)
+        return gh_sharded_fused_step_pipelined_dev(comm, cur_rgb_buf, next_rgb_buf, edge, width, rows, channels, mode, stream);
+    if (gh_comm_halo_timeouts(c))
+        return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
+                            gh_comm_halo_timeouts(c));
+    if (int rc = halo_flag_guard(c, s)) return rc;
+    GhHaloWait hw = halo_flag_launch_args(c);
+    if (c->stream_buf == cur_rgb_buf) {
+        hw.wait_epoch = c->stream_xepoch;                 // on its way since the previous call
+    } else if (int rc = halo_flag_exchange(c, hw, cur_rgb_buf, rb, rows, up, down, &hw.wait_epoch)) {
+        halo_flag_release(s, hw);
+        return rc;
+    }
+    c->stream_buf = nullptr;
+    if (next_rgb_buf && next_rgb_buf != cur_rgb_buf) {
+        // next's rows 1 / rows are in place (enqueued on s before this call): the exchange may start as soon as this launch has begun
+        if (int rc = halo_flag_exchange(c, hw, next_rgb_buf, rb, rows, up, down, &c->stream_xepoch)) { halo_flag_release(s, hw); return rc; }
+        c->stream_buf = next_rgb_buf;
+    }
+    const int rc = gh_fused_rows_halo_wait(cur_rgb_buf + rb, edge, width, rows, channels, mode, up < 0, down < 0, stream, &hw);
+    if (rc != GH_OK) halo_flag_release(s, hw);
+    return rc;
 }
 
 int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels, int mode, gh_stream_t stream)

@@ -44,7 +44,7 @@ void gh_note_kernel(const char *name);
 //   started  the shard kernel's first workgroup stores the step's epoch there when it begins -- by stream order every earlier piece of
 //            work on the caller's stream has completed then (the rows to send are in place, the previous step has read its halo rows);
 //            the side stream polls it in front of the exchange;
-//   flag     set to the epoch behind the ncclRecv; only the workgroups of the first / last band, whose rows depend on a halo row, poll
+//   flag     set to the exchange's number behind the ncclRecv; only the workgroups of the first / last band, whose rows depend on a halo row, poll
 //            it before they issue their first load; every other workgroup starts at once.
 // A wait that outlasts `ticks` of the 100 MHz constant clock gives up, counts itself in *timeouts (host-mapped memory: the next sharded
 // call sees it without a synchronisation and fails) and lets the wave finish -- every wave reaches its exit whatever happens to the
@@ -53,8 +53,10 @@ struct GhHaloWait {
     const uint32_t *flag;
     uint32_t *started;
     uint32_t *timeouts;
-    uint32_t epoch;
+    uint32_t epoch;               // what the kernel's first workgroup stores into `started`
+    uint32_t wait_epoch;          // what `flag` must have reached before an edge band may request its halo row
     uint32_t pad;                 // host side: 1 = "would this frame run a kernel form that carries the wait?" (GH_OK / GH_NO_FLAG_FORM, nothing launched)
+    uint32_t pad2;
     unsigned long long ticks;
 };
 constexpr int GH_NO_FLAG_FORM = -100;      // internal: this frame shape runs a kernel form without the flag wait (narrow frames, per-pixel kernels)
@@ -126,7 +128,7 @@ __device__ __forceinline__ void gh_halo_wait(const GhHaloWait &hw)
     GH_HALO_TRACE_AT(hw.flag, 3);
     for (;;) {
         const uint32_t v = __hip_atomic_load(hw.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int32_t)(v - hw.epoch) >= 0) { GH_HALO_TRACE_AT(hw.flag, 4); return; }
+        if ((int32_t)(v - hw.wait_epoch) >= 0) { GH_HALO_TRACE_AT(hw.flag, 4); return; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > hw.ticks) {
             if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(hw.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;

@@ -159,5 +159,7 @@ def test_loopback_rehearsal_drives_the_native_step_forms():
     assert out["exchange_fallback"] is False and out["exchange_issuer"].startswith("libgrayhip")
     assert out["shard_step_form"].startswith("halo flag")
     assert out["step_forms"]["single_frame"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.01)
-    assert out["step_forms"]["pipelined"]["exchanges_per_step"] <= 0.35            # four frames per exchange (+ the cold start)
+    assert out["step_forms"]["pipelined"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.02)       # one per frame, beside the previous frame's launch
+    assert out["step_forms"]["pipelined_batched"]["exchanges_per_step"] <= 0.35    # four frames per exchange (+ the cold start)
+    assert out["step_forms"]["stream_of_frames"]["exchanges_per_step"] if "exchanges_per_step" in out["step_forms"]["stream_of_frames"] else True
     assert out["halo_flag_timeouts"] == 0

@@ -199,6 +199,57 @@ def test_shard_kernel_beside_an_exchange_takes_fat_bands(pkg, oracle, native_com
     del alone
 
 
+@pytest.mark.parametrize("w,h,c,nbuf", [(2064, 37, 3, 3), (16384, 70, 3, 2), (1031, 33, 4, 4), (4096, 2048 // 8, 3, 8), (512, 20, 3, 3), (2048, 40, 3, 1)])
+def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, nbuf):
+    """gh_sharded_fused_stream_step_dev: frame k is filtered by one launch while the halo rows of frame k + 1 travel beside it, the two
+    sides meeting through the polled dwords only.  All frames differ and their halo rows start out poisoned, so a halo that reached
+    the wrong buffer, arrived late or was never exchanged changes the result; then the frames are replaced between steps (the next
+    frame's rows must be in place before the step that announces it).  (512 wide: no flag form -- the event-based pipelined step.)"""
+    t = torch_mod
+
+    def expected(img):
+        e = oracle.sobel(oracle.gray_to_plane(_replicate_padded(img), 0))[1:-1].copy()
+        e[:, 0] = 0
+        e[:, -1] = 0
+        return e
+
+    native_comm.set_loopback(True)
+    try:
+        frames = [oracle.frame_rand(w, h, c, seed=300 + 7 * i + w) for i in range(nbuf)]
+        bufs = []
+        for img in frames:
+            b = t.full((h + 2, w, c), 0x77, dtype=t.uint8, device="cuda")
+            b[1:h + 1] = dev(t, img)
+            bufs.append(b)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_stream_step(bufs, edge, h, 0)
+        n0 = native_comm.exchange_count()
+        for k in range(2 * nbuf + 1):                                   # synchronised: every step checked
+            step(k)
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[k % nbuf])), k
+        if nbuf > 1 and w >= 1024:
+            assert native_comm.exchange_count() - n0 == 2 * nbuf + 2       # one exchange per frame + the cold start of the first
+        k = 2 * nbuf + 1
+        results = []
+        for _ in range(3 * nbuf + 2):                                   # unsynchronised, frames replaced on the stream between steps
+            nxt = (k + 1) % nbuf
+            if nbuf > 2:                                                # a ring of 1 or 2 has no buffer that is neither cur nor being announced
+                frames[nxt] = oracle.frame_rand(w, h, c, seed=1000 + k)
+                bufs[nxt][1:h + 1] = dev(t, frames[nxt])
+                bufs[nxt][0] = 0x33
+                bufs[nxt][h + 1] = 0x44
+            step(k)
+            results.append((edge.clone(), expected(frames[k % nbuf])))
+            k += 1
+        t.cuda.synchronize()
+        for i, (got, want) in enumerate(results):
+            assert np.array_equal(got.cpu().numpy(), want), i
+        assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
+    finally:
+        native_comm.set_loopback(False)
+
+
 def test_halo_flag_epochs_restart_before_they_could_wrap(pkg, oracle, torch_mod, monkeypatch):
     """The handshake compares 32-bit epochs; at 0x7ffffff0 the step drains both streams once and starts again from zero.  A
     communicator that begins 12 steps before that point runs 40 steps across it: every result right, no wait timed out."""

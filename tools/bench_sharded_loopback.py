@@ -22,6 +22,9 @@ for world in WORLDS:
     ring8 = [buf, buf2, buf3] + [buf.clone() for _ in range(5)]
     bstep4 = comm.bind_fused_step_batched(ring8, edge, rows, 0, 4)
     bstep2 = comm.bind_fused_step_batched(ring8, edge, rows, 0, 2)
+    sstep8 = comm.bind_fused_stream_step(ring8, edge, rows, 0)
+    def stream_flag8():
+        sstep8(cnt[0]); cnt[0] += 1
     ring_steps = [comm.bind_fused_step(b, edge, rows, 0) for b in ring8]
     def stream8():
         ring_steps[cnt[0] % 8](); cnt[0] += 1
@@ -36,7 +39,7 @@ for world in WORLDS:
         pstep3(cnt[0]); cnt[0] += 1
     for name, fn in (("native sharded step (GH_SHARD_STEP_FORM: 2 halo flag, 1 serial, 0 events)", step), ("native pipelined step, halo 1 frame ahead", piped),
                      ("native pipelined step, halo 2 frames ahead", piped3), ("native batched step, halos of 4 frames per exchange (ring of 8)", batched4),
-                     ("native batched step, halos of 2 frames per exchange (ring of 8)", batched2), ("single-frame step over a ring of 8 different frames", stream8), ("single launch, no exchange", whole)):
+                     ("native batched step, halos of 2 frames per exchange (ring of 8)", batched2), ("single-frame step over a ring of 8 different frames", stream8), ("stream step (halo of the next frame beside this launch, flags; ring of 8)", stream_flag8), ("single launch, no exchange", whole)):
         if ONLY and ONLY not in name: continue
         cnt[0] = 0
         for _ in range(24): fn()
