@@ -108,6 +108,9 @@ int main() {
             for (int k = 0; k < 3; ++k) OK(gh_sharded_fused_step_dev(comm, (uint8_t *)bufs[k % 3], (uint8_t *)edge, w, rows, 3, 0, nullptr));
         }
         unsetenv("GH_SHARD_STEP_FORM");
+        for (int k = 0; k < 7; ++k)         // the stream step: halo rows of the next frame beside this launch (flags), ring of three
+            OK(gh_sharded_fused_stream_step_dev(comm, (uint8_t *)bufs[k % 3], (uint8_t *)bufs[(k + 1) % 3], (uint8_t *)edge, w, rows, 3, 0, nullptr));
+        OK(gh_sharded_fused_stream_step_dev(comm, (uint8_t *)bufs[0], nullptr, (uint8_t *)edge, w, rows, 3, 0, nullptr));
         void *luma = nullptr, *conv_out = nullptr, *mm = nullptr;
         OK(gh_malloc(&luma, (size_t)(rows + 2) * w));
         OK(gh_malloc(&conv_out, (size_t)rows * w * 3));
@@ -123,7 +126,7 @@ int main() {
         OK(gh_mean_gray_minmax_dev((const uint8_t *)bufs[0], (uint8_t *)conv_out, (size_t)rows * w, (int32_t *)mm, nullptr));
         OK(gh_comm_allreduce_minmax_i32_dev(comm, (int32_t *)mm, nullptr));
         OK(gh_stream_sync(nullptr));
-        if (gh_comm_exchange_count(comm) - x0 != 12 + 1 + 1 + 3) { printf("FAIL exchange count %llu\n", gh_comm_exchange_count(comm) - x0); return 1; }
+        if (gh_comm_exchange_count(comm) - x0 != 12 + 8 + 1 + 1 + 1 + 3) { printf("FAIL exchange count %llu\n", gh_comm_exchange_count(comm) - x0); return 1; }
         if (gh_comm_halo_timeouts(comm) != 0) { printf("FAIL halo-flag wait timed out\n"); return 1; }
         int cu = 0, xcd = 0;
         OK(gh_device_topology(&cu, &xcd));
