@@ -95,10 +95,20 @@ def run(secs: float, seed: int, verbose: bool = True):
                 for _ in range(int(rnd.randint(1, 4))):                                # back-to-back steps: step k+1's exchange vs step k's reads
                     f1()
                     f2()
-                shard = (e1, e2, want_s)
+                e3 = None
+                if rnd.randint(2) == 0:                                                # the stream step over a ring of two or three copies of the frame
+                    ring = [buf] + [buf.clone() for _ in range(int(rnd.randint(1, 3)))]
+                    for b_ in ring:
+                        b_[0] = 0x3C
+                        b_[h + 1] = 0xC3
+                    e3 = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+                    f3 = comm.bind_fused_stream_step(ring, e3, h, mode)
+                    for k_ in range(int(rnd.randint(1, 6))):
+                        f3(k_)
+                shard = (e1, e2, want_s) if e3 is None else (e1, e2, want_s, e3)
             torch.cuda.synchronize()
             if shard is not None:
-                for e_ in shard[:2]:
+                for e_ in shard[:2] + shard[3:]:
                     n += 1
                     if not np.array_equal(e_.cpu().numpy(), shard[2]):
                         bad += 1
