@@ -115,8 +115,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_stream(const uin
         for (int j = 0; j < C; ++j) {
             const int i = ch * C + j;
             // bytes x-4..x-1 (left lane's q.w) and x+16..x+19 (right lane's q.x)
-            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[j].w, 0x138, 0xf, 0xf, false);
-            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, false);
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[j].w, 0x138, 0xf, 0xf, true);
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, true);
             if (lane == 0) ql = hb[j];
             if (lane == 63) qr = hb[j];
             // p[-3..18] as floats; pair layout G[m] = (p[m-3], p[m+5]), m = 0..13
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
         }
         const uint8_t *slotp = &ring[wave][j % D][0];
         uint4 q = *reinterpret_cast<const uint4 *>(slotp + PRE + 16 * lane);
-        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, true);   // wave_shr:1  lane l <- lane l-1
+        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
         if (UNAL) {
             const uint32_t fl = *reinterpret_cast<const uint32_t *>(slotp + PRE - 4);
             const uint2 fr = *reinterpret_cast<const uint2 *>(slotp + PRE + STRIP_PX);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_conv3x3_dma(const uint8_
             if (lane == 63) qr = fr.x;
             if (UNAL == 2) {                                         // the strip starts at byte sh of the lane grid
                 const uint32_t sh = (uint32_t)(uintptr_t)strip_row(i) & 3u;
-                uint32_t qr2 = __builtin_amdgcn_update_dpp(0u, q.y, 0x130, 0xf, 0xf, false);
+                uint32_t qr2 = __builtin_amdgcn_update_dpp(0u, q.y, 0x130, 0xf, 0xf, true);
                 if (lane == 63) qr2 = fr.y;
                 ql = __builtin_amdgcn_alignbyte(q.x, ql, sh);
                 q.x = __builtin_amdgcn_alignbyte(q.y, q.x, sh);

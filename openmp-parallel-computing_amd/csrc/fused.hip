@@ -87,8 +87,8 @@ __device__ __forceinline__ uint4 fused_row(stream_core::StateF2 &st, const uint3
     // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element expression reads
     //  element 0 of the vector with this hipcc, which silently turned G[8].y into G[8].x)
     const float own15 = G[8].y, own0 = G[1].x;
-    float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own15), 0x138, 0xf, 0xf, false));
-    float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own0), 0x130, 0xf, 0xf, false));
+    float pl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own15), 0x138, 0xf, 0xf, true));
+    float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(uint32_t, own0), 0x130, 0xf, 0xf, true));
     if (lane == 0) pl = hl;
     if (lane == 63) pr = hl;
     G[0] = f32x2{pl, G[8].x};        // (p[-1], p[7])
@@ -411,7 +411,7 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
             uint32_t hl = fl, hr = fr.x;
             if (UNAL == 2) {                                         // the strip starts at byte sh of the lane grid
                 const uint32_t sh = (uint32_t)(uintptr_t)strip_row(i) & 3u;
-                uint32_t nx = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+                uint32_t nx = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
                 if (lane == 63) nx = fr.x;
                 hl = __builtin_amdgcn_alignbyte(wv[0], fl, sh);
                 hr = __builtin_amdgcn_alignbyte(fr.y, fr.x, sh);

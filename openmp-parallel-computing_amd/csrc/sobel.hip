@@ -76,8 +76,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int i = ch * C + j;
-            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[j].w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[j].w, 0x138, 0xf, 0xf, true);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[j].x, 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
             if (lane == 0) ql = hb[j] << 24;
             if (lane == 63) qr = hb[j];
             uint4 out;
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         uint2 hh;
         if (UNAL) hh = make_uint2(*reinterpret_cast<const uint32_t *>(slotp + PRE - 4), *reinterpret_cast<const uint32_t *>(slotp + PRE + STRIP_PX));
         else hh = *reinterpret_cast<const uint2 *>(slotp + STRIP_PX);
-        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+        uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, true);   // wave_shr:1  lane l <- lane l-1
+        uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
         if (lane == 0) ql = UNAL ? hh.x : hh.x << lsh;
         if (lane == 63) qr = UNAL ? hh.y : hh.y >> rsh;
         if (UNAL == 2) {                                             // the strip starts at byte s of the lane grid
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         const bool zero_row = may_be_border_row && ((y == 0 && zero_top) || (y == rows - 1 && zero_bot));
         auto strip = [&](auto sub_c, StateF2 &st, uint4 q, uint32_t left_of_lane0, uint32_t right_of_lane63) {
             constexpr int SUB = decltype(sub_c)::value;
-            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q.w, 0x138, 0xf, 0xf, true);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q.x, 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
             if (lane == 0) ql = left_of_lane0;
             if (lane == 63) qr = right_of_lane63;
             if (UNAL == 2) {
@@ -565,8 +565,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma4(const uint8_t
             // the pixel left of strip k is strip k-1's last (lane 63, top byte of q.w), the pixel right of it strip k+1's first (lane 0, low byte of q.x)
             const uint32_t left_of_lane0 = k == 0 ? hh.x : (uint32_t)__builtin_amdgcn_readlane((int)q[k > 0 ? k - 1 : 0].w, 63);
             const uint32_t right_of_lane63 = k == NS - 1 ? hh.y : (uint32_t)__builtin_amdgcn_readfirstlane((int)q[k < NS - 1 ? k + 1 : 0].x);
-            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[k].w, 0x138, 0xf, 0xf, false);   // wave_shr:1  lane l <- lane l-1
-            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[k].x, 0x130, 0xf, 0xf, false);   // wave_shl:1  lane l <- lane l+1
+            uint32_t ql = __builtin_amdgcn_update_dpp(0u, q[k].w, 0x138, 0xf, 0xf, true);   // wave_shr:1  lane l <- lane l-1
+            uint32_t qr = __builtin_amdgcn_update_dpp(0u, q[k].x, 0x130, 0xf, 0xf, true);   // wave_shl:1  lane l <- lane l+1
             if (lane == 0) ql = left_of_lane0;
             if (lane == 63) qr = right_of_lane63;
             uint4 out;
