@@ -830,7 +830,7 @@ def main() -> int:
                     step_form = 1
                     single_ok = single_agrees()
                     exchange_note = "the halo-flag form of the single-frame step disagreed with torch.distributed; serial form (exchange, then launch) in its place"
-                same = same and single_ok
+                pipe_ok, same = same, single_ok          # `same` decides whether the native path is adopted at all: the single-frame step (`value`)
                 same_b = False
                 if same and fused and bstep is not None:
                     same_b = True
@@ -839,14 +839,19 @@ def main() -> int:
                         torch.cuda.synchronize()
                         same_b = same_b and bool(torch.equal(edge_native, runners[k % NBUF].edge))
             except Exception as exc:
-                same, same_b, exchange_note = False, False, f"native step failed on rank {rank}: {exc}"
+                same, same_b, pipe_ok, exchange_note = False, False, False, f"native step failed on rank {rank}: {exc}"
             if all_ranks_agree(same or rehearsal_loopback):
                 exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
                             + ("pipelined form: the halo rows of frame k+1 travel beside the launch on frame k, no event between the streams"
                                if fused else f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed"))
-                pipelined_impl, edge_of = native_step, (lambda k: edge_native)
                 single_impl, single_edge = native_single, edge_native
                 stream_impl = native_stream
+                edge_of = lambda k: edge_native
+                if all_ranks_agree(pipe_ok or rehearsal_loopback):
+                    pipelined_impl = native_step
+                else:                              # the stream step disagreed: the checked single-frame step on every frame in its place
+                    pipelined_impl = native_stream
+                    exchange_note = exchange_note or "the pipelined stream step disagreed with torch.distributed on the first frames; the single-frame step per frame in its place"
                 if fused and bstep is not None and all_ranks_agree(same_b or rehearsal_loopback):
                     batched_impl = bstep          # (k runs on from 0 through run-in, warm-up and timed steps: a batch request every BATCH-th step)
                 elif fused and bstep is not None:
