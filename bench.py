@@ -782,13 +782,13 @@ def main() -> int:
                     # batched form: the halos of BATCH future frames in one group, a step = one launch (checked below like the other)
                     bstep = native.bind_fused_step_batched(halo_bufs, edge_native, rows, mode, BATCH) if args.halo_batch else None
                 else:
-                    pstep = native.bind_sobel_step_pipelined(halo_bufs, edge_native, rows, ahead=AHEAD)
+                    pstep = native.bind_sobel_stream_step(halo_bufs, edge_native, rows)
                     grays = [backend.bind_gray_to_plane(rgbs[i], halo_bufs[i][1:rows + 1]) for i in range(NBUF)]
                     for g_ in grays:
                         g_()          # prologue: luma of every frame of the ring exists before its halo is first requested
 
                     def native_step(k):
-                        grays[(k + AHEAD) % NBUF]()      # luma of the frame whose halo is requested in this step
+                        grays[(k + 1) % NBUF]()          # luma of the frame whose halo rows this step sends on their way
                         pstep(k)
                     sstep = native.bind_sobel_step(halo_bufs[0], edge_native, rows)
 
@@ -842,8 +842,7 @@ def main() -> int:
                 same, same_b, pipe_ok, exchange_note = False, False, False, f"native step failed on rank {rank}: {exc}"
             if all_ranks_agree(same or rehearsal_loopback):
                 exchange = ("libgrayhip RCCL communicator (csrc/comm.hip): ncclSend/ncclRecv group on a side stream, issued from C++; "
-                            + ("pipelined form: the halo rows of frame k+1 travel beside the launch on frame k, no event between the streams"
-                               if fused else f"pipelined form: the halo rows of frame k+{AHEAD} travel while frame k is processed"))
+                            + "pipelined form: the halo rows of frame k+1 travel beside the launch on frame k, no event between the streams")
                 single_impl, single_edge = native_single, edge_native
                 stream_impl = native_stream
                 edge_of = lambda k: edge_native

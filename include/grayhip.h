@@ -240,6 +240,9 @@ GH_API int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma
  * back to gh_sharded_fused_step_pipelined_dev. */
 GH_API int gh_sharded_fused_stream_step_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *next_rgb_buf, uint8_t *edge, int width, int rows,
                                             int channels, int mode, gh_stream_t stream);
+/* the same for the split pipeline: buffers of luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */
+GH_API int gh_sharded_sobel_stream_step_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *next_luma_buf, uint8_t *edge, int width, int rows,
+                                            gh_stream_t stream);
 /* Batched prefetch for the pipelined steps: the halo rows of n (1..16) frame buffers -- (rows + 2) rows of row_bytes each, rows
  * 1 / rows in place (enqueued on `stream`) -- are exchanged in ONE ncclGroup on the side stream, one event behind all of them.
  * The pipelined steps that later run on these buffers (prefetch = NULL) find their halos requested: the first waits for the

@@ -73,6 +73,7 @@ SIGNATURES = {
     "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_stream_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_sharded_sobel_stream_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sharded_prefetch_halos_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int, _stream]),
     "gh_sharded_prefetch_reset": (C.c_int, [C.c_void_p]),

@@ -598,11 +598,48 @@ int gh_sharded_sobel_step_pipelined_dev(gh_comm_t comm, uint8_t *cur_luma_buf, u
     });
 }
 
+}  // extern "C"
+
 // Stream of frames in the halo-flag way: `cur` is filtered by ONE launch whose edge bands wait (in the kernel, in front of their halo row)
 // for the exchange that the PREVIOUS call sent on its way when `cur` was its `next`; the halo rows of `next` travel on the side stream
 // beside this launch, behind `started` -- no event, no stream-level wait.  By the time a launch needs its halo row the exchange has had a
 // whole launch to complete.  cur's halo rows not on their way (first call, another buffer): they are exchanged beside this launch, as in
-// the single-frame step.  Frames whose kernel form carries no flag wait: the event-based pipelined step.
+// the single-frame step.  Frames whose kernel form carries no flag wait: the event-based pipelined step (`fallback`).
+template <typename LaunchWait, typename Plain, typename Fallback>
+static int sharded_stream_step(Comm *c, uint8_t *cur, uint8_t *next, size_t rb, int rows, hipStream_t s, LaunchWait launch_wait /* (tb, bb, hw) */,
+                               Plain plain /* () : no neighbours */, Fallback fallback /* () */)
+{
+    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback) up = down = c->rank;
+    if (up < 0 && down < 0) return plain();
+    GhHaloWait probe{};
+    probe.pad = 1;
+    const int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
+    if (form != 2 || launch_wait(up < 0, down < 0, probe) != GH_OK) return fallback();
+    if (gh_comm_halo_timeouts(c))
+        return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
+                            gh_comm_halo_timeouts(c));
+    if (int rc = halo_flag_guard(c, s)) return rc;
+    GhHaloWait hw = halo_flag_launch_args(c);
+    if (c->stream_buf == cur) {
+        hw.wait_epoch = c->stream_xepoch;                 // on its way since the previous call
+    } else if (int rc = halo_flag_exchange(c, hw, cur, rb, rows, up, down, &hw.wait_epoch)) {
+        halo_flag_release(s, hw);
+        return rc;
+    }
+    c->stream_buf = nullptr;
+    if (next && next != cur) {
+        // next's rows 1 / rows are in place (enqueued on s before this call): the exchange may start as soon as this launch has begun
+        if (int rc = halo_flag_exchange(c, hw, next, rb, rows, up, down, &c->stream_xepoch)) { halo_flag_release(s, hw); return rc; }
+        c->stream_buf = next;
+    }
+    const int rc = launch_wait(up < 0, down < 0, hw);
+    if (rc != GH_OK) halo_flag_release(s, hw);
+    return rc;
+}
+
+extern "C" {
+
 int gh_sharded_fused_stream_step_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8_t *next_rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream)
 {
@@ -611,36 +648,25 @@ int gh_sharded_fused_stream_step_dev(gh_comm_t comm, uint8_t *cur_rgb_buf, uint8
     if (width == 0 || rows == 0) return GH_OK;
     GH_REQUIRE(cur_rgb_buf && edge, "null pointer");
     Comm *c = static_cast<Comm *>(comm);
-    hipStream_t s = (hipStream_t)stream;
     const size_t rb = (size_t)width * channels;
-    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
-    if (c->loopback) up = down = c->rank;
-    if (up < 0 && down < 0) return gh_gray_sobel_fused_rows_dev(cur_rgb_buf + rb, edge, width, rows, channels, mode, 1, 1, stream);
-    GhHaloWait probe{};
-    probe.pad = 1;
-    const int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
-    if (form != 2 || gh_fused_rows_halo_wait(cur_rgb_buf + rb, edge, width, rows, channels, mode, up < 0, down < 0, stream, &probe) != GH_OK)
-        return gh_sharded_fused_step_pipelined_dev(comm, cur_rgb_buf, next_rgb_buf, edge, width, rows, channels, mode, stream);
-    if (gh_comm_halo_timeouts(c))
-        return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
-                            gh_comm_halo_timeouts(c));
-    if (int rc = halo_flag_guard(c, s)) return rc;
-    GhHaloWait hw = halo_flag_launch_args(c);
-    if (c->stream_buf == cur_rgb_buf) {
-        hw.wait_epoch = c->stream_xepoch;                 // on its way since the previous call
-    } else if (int rc = halo_flag_exchange(c, hw, cur_rgb_buf, rb, rows, up, down, &hw.wait_epoch)) {
-        halo_flag_release(s, hw);
-        return rc;
-    }
-    c->stream_buf = nullptr;
-    if (next_rgb_buf && next_rgb_buf != cur_rgb_buf) {
-        // next's rows 1 / rows are in place (enqueued on s before this call): the exchange may start as soon as this launch has begun
-        if (int rc = halo_flag_exchange(c, hw, next_rgb_buf, rb, rows, up, down, &c->stream_xepoch)) { halo_flag_release(s, hw); return rc; }
-        c->stream_buf = next_rgb_buf;
-    }
-    const int rc = gh_fused_rows_halo_wait(cur_rgb_buf + rb, edge, width, rows, channels, mode, up < 0, down < 0, stream, &hw);
-    if (rc != GH_OK) halo_flag_release(s, hw);
-    return rc;
+    return sharded_stream_step(c, cur_rgb_buf, next_rgb_buf, rb, rows, (hipStream_t)stream,
+        [&](int tb, int bb, const GhHaloWait &hw) { return gh_fused_rows_halo_wait(cur_rgb_buf + rb, edge, width, rows, channels, mode, tb, bb, stream, &hw); },
+        [&] { return gh_gray_sobel_fused_rows_dev(cur_rgb_buf + rb, edge, width, rows, channels, mode, 1, 1, stream); },
+        [&] { return gh_sharded_fused_step_pipelined_dev(comm, cur_rgb_buf, next_rgb_buf, edge, width, rows, channels, mode, stream); });
+}
+
+int gh_sharded_sobel_stream_step_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint8_t *next_luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    if (width == 0 || rows == 0) return GH_OK;
+    GH_REQUIRE(cur_luma_buf && edge, "null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    const size_t rb = (size_t)width;
+    return sharded_stream_step(c, cur_luma_buf, next_luma_buf, rb, rows, (hipStream_t)stream,
+        [&](int tb, int bb, const GhHaloWait &hw) { return gh_sobel_rows_halo_wait(cur_luma_buf + rb, edge, width, rows, tb, bb, stream, &hw); },
+        [&] { return gh_sobel_u8_rows_dev(cur_luma_buf + rb, edge, width, rows, 1, 1, stream); },
+        [&] { return gh_sharded_sobel_step_pipelined_dev(comm, cur_luma_buf, next_luma_buf, edge, width, rows, stream); });
 }
 
 int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels, int mode, gh_stream_t stream)

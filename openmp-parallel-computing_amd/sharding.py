@@ -222,6 +222,20 @@ class NativeHaloComm:
         return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + 1) % n] if n > 1 else None, dst, w, rows, c, mode, torch.cuda.current_stream().cuda_stream),
                              "gh_sharded_fused_stream_step_dev")
 
+    def bind_sobel_stream_step(self, lumas, edge, rows):
+        """The split pipeline's twin of bind_fused_stream_step: lumas are (rows+2, w) luma buffers; the luma of frame k + 1 must be in its
+        buffer before step k is called."""
+        import torch
+        w = lumas[0].shape[1]
+        for b in lumas:
+            assert tuple(b.shape) == (rows + 2, w) and b.is_contiguous()
+        assert tuple(edge.shape) == (rows, w) and edge.is_contiguous()
+        fn, chk, h, dst = self.lib.gh_sharded_sobel_stream_step_dev, self.abi.check, self.handle, edge.data_ptr()
+        chk(self.lib.gh_sharded_prefetch_reset(h), "gh_sharded_prefetch_reset")
+        ptrs, n = [b.data_ptr() for b in lumas], len(lumas)
+        return lambda k: chk(fn(h, ptrs[k % n], ptrs[(k + 1) % n] if n > 1 else None, dst, w, rows, torch.cuda.current_stream().cuda_stream),
+                             "gh_sharded_sobel_stream_step_dev")
+
     def bind_fused_step_batched(self, bufs, edge, rows, mode, batch):
         """Stream of frames cycling through len(bufs) >= 2 * batch buffers: every `batch` steps the halo rows of the NEXT `batch`
         frames are exchanged in one group (gh_sharded_prefetch_halos_dev) while the current ones are processed; a step is one

@@ -246,6 +246,22 @@ def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, 
         for i, (got, want) in enumerate(results):
             assert np.array_equal(got.cpu().numpy(), want), i
         assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
+        # the split pipeline's twin: luma buffers, luma halo rows
+        if c == 3:
+            backend = pkg.sharding.HipBackend(0)
+            lumas = []
+            for img in frames:
+                l = t.full((h + 2, w), 0x5C, dtype=t.uint8, device="cuda")
+                backend.gray_to_plane(dev(t, img), l[1:h + 1])
+                lumas.append(l)
+            step2 = native_comm.bind_sobel_stream_step(lumas, edge, h)
+            for k in range(2 * nbuf + 2):
+                step2(k)
+                if k % 3 == 0:
+                    t.cuda.synchronize()
+                    assert np.array_equal(edge.cpu().numpy(), expected(frames[k % nbuf])), ("sobel", k)
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[(2 * nbuf + 1) % nbuf]))
     finally:
         native_comm.set_loopback(False)
 
