@@ -49,6 +49,32 @@ def main():
         s_lo, s_hi = max(lo, t_lo), min(hi, t_hi)
         rgb[s_lo - lo:s_hi - lo] = tile[s_lo - t_lo:s_hi - t_lo]
     t_gen = time.time() - t0
+    # what the link itself gives: one large pinned host-to-device copy (and, after it, both directions at once), timed with events
+    h2d_ceiling = duplex_ceiling = None
+    try:
+        nb = min(rgb_t.numel(), 2 << 30)
+        dev_buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        back = torch.empty(nb // 3, dtype=torch.uint8).pin_memory()
+        src = rgb_t.view(-1)[:nb]
+        s2 = torch.cuda.Stream()
+        for k in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dev_buf.copy_(src, non_blocking=True)
+            if k == 2:
+                with torch.cuda.stream(s2):
+                    back.copy_(dev_buf[:nb // 3], non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            s2.synchronize()
+            gbs = nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            if k == 1:
+                h2d_ceiling = gbs
+            if k == 2:
+                duplex_ceiling = gbs
+        del dev_buf, back
+    except Exception:
+        pass
     best = None
     for _ in range(a.reps):
         if world > 1:
@@ -109,8 +135,11 @@ def main():
                "parity_full_frame": (None if full_ok is None else ("ok: every row of the edge plane == oracle" if full_ok else "MISMATCH")),
                "parity_check_s": round(t_chk, 1), "edge_sum": edge_sum, "edge_sha256": digest,
                # this configuration is bound by PCIe H2D (Gen5 x16: 64 GB/s per GPU and direction), not by HBM
+               "h2d_copy_ceiling_GB/s": round(h2d_ceiling, 2) if h2d_ceiling else None,
+               "h2d_copy_ceiling_with_d2h_beside_GB/s": round(duplex_ceiling, 2) if duplex_ceiling else None,
                "roofline": {"bound": "pcie", "achieved": round(3 * npix / best / 1e9 / world, 2), "peak": 64.0, "unit": "GB/s",
                             "frac": round(3 * npix / best / 1e9 / world / 64.0, 4),
+                            "frac_of_copy_ceiling": round(3 * npix / best / 1e9 / world / h2d_ceiling, 4) if h2d_ceiling else None,
                             "what": "host-to-device bytes per GPU (3 B/px) / wall time of the streamed call; the 1 B/px edge plane returns on the other direction concurrently"}}
         print(json.dumps(out))
     if world > 1:
