@@ -194,7 +194,7 @@ GH_API int gh_comm_allreduce_minmax_i32_dev(gh_comm_t comm, int32_t *minmax_dev,
 GH_API unsigned long long gh_comm_exchange_count(gh_comm_t comm);
 /* Halo-flag waits that gave up (see gh_sharded_*_step_dev): 0 in every healthy run.  Non-zero means an exchange took longer than
  * GH_HALO_WAIT_MS (default 10000) beside a launch whose edge bands were waiting for it; that step's edge rows are invalid and every
- * later sharded step on this communicator fails. */
+ * later halo-flag step on this communicator fails until gh_comm_set_step_form acknowledges it (the serial and event forms keep working). */
 GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
 /* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default (GH_SHARD_STEP_FORM=2, shards
  * that run an LDS-DMA ring kernel: 1024 columns and more): the one-row exchange runs on the communicator's side stream BESIDE one launch

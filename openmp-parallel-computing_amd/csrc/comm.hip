@@ -225,7 +225,9 @@ int gh_comm_set_step_form(gh_comm_t comm, int form)
 {
     GH_REQUIRE(comm, "null communicator");
     GH_REQUIRE(form >= -1 && form <= 2, "form must be -1, 0, 1 or 2");
-    static_cast<Comm *>(comm)->step_form = form;
+    Comm *c = static_cast<Comm *>(comm);
+    c->step_form = form;
+    if (c->timeouts_host) __atomic_store_n(c->timeouts_host, 0u, __ATOMIC_RELEASE);      // choosing a form acknowledges waits that gave up earlier
     return GH_OK;
 }
 
@@ -394,9 +396,6 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
     if (c->loopback) up = down = c->rank;      // a middle shard whose neighbours are itself: halo = its own edge rows
     if (up < 0 && down < 0) return launch(0, rows, 1, 1);
-    if (gh_comm_halo_timeouts(c))
-        return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
-                            gh_comm_halo_timeouts(c));
     uint8_t *send_up = buf + row_bytes, *recv_up = buf, *send_down = buf + (size_t)rows * row_bytes, *recv_down = buf + (size_t)(rows + 1) * row_bytes;
     // Three forms (GH_SHARD_STEP_FORM / gh_comm_set_step_form; loopback rehearsal, 16384-wide shards of 2048 / 4096 / 8192 rows, us per step;
     // tools/sweep.py shard_forms):
@@ -419,6 +418,11 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         return launch(0, rows, up < 0, down < 0);
     }
     if (form == 2) {
+        // (a wait of an earlier halo-flag step that gave up -- its edge rows were computed from stale halo rows -- fails every later
+        //  halo-flag step of this communicator; gh_comm_set_step_form acknowledges it, e.g. on the way to the serial form)
+        if (gh_comm_halo_timeouts(c))
+            return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
+                                gh_comm_halo_timeouts(c));
         // No event in either direction: the side stream polls `started` (stored by the shard kernel's first workgroup: everything
         // enqueued on s before this step has completed by then -- the rows to send are in place, the previous step has read its halo
         // rows), exchanges, and sets `flag`, which the shard kernel's edge bands poll.

@@ -301,6 +301,54 @@ def test_halo_flag_epochs_restart_before_they_could_wrap(pkg, oracle, torch_mod,
         comm.close()
 
 
+def test_a_halo_wait_that_gives_up_is_reported_not_hidden(pkg, oracle, torch_mod, monkeypatch):
+    """Every in-kernel wait is bounded (GH_HALO_WAIT_MS).  With the bound at zero the edge bands of a 2048-row shard ask for their halo
+    row before the exchange has landed and give up: the wave still finishes (the launch drains), the give-up is counted in host-mapped
+    memory, the NEXT halo-flag step fails loudly, the serial form keeps working, and choosing a form acknowledges the count."""
+    t = torch_mod
+    w, h = 16384, 2048
+    comm = pkg.sharding.NativeHaloComm(0, 1)
+    try:
+        comm.set_loopback(True)
+        img = oracle.frame_rand(w, h, 3, seed=31)
+        buf = t.zeros((h + 2, w, 3), dtype=t.uint8, device="cuda")
+        buf[1:h + 1] = dev(t, img)
+        buf[0] = buf[1]
+        buf[h + 1] = buf[h]
+        want = pkg.hostapi.gray_sobel_fused_rows(buf, t.empty((h, w), dtype=t.uint8, device="cuda"), h, 0, False, False).clone()
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = comm.bind_fused_step(buf, edge, h, 0)
+        step()
+        t.cuda.synchronize()
+        assert t.equal(edge, want) and pkg.abi.load().gh_comm_halo_timeouts(comm.handle) == 0
+        monkeypatch.setenv("GH_HALO_WAIT_MS", "0")
+        buf[0] = 0x11
+        buf[h + 1] = 0x22
+        step()
+        t.cuda.synchronize()                                   # the launch drained although its waits gave up
+        monkeypatch.delenv("GH_HALO_WAIT_MS")
+        gave_up = pkg.abi.load().gh_comm_halo_timeouts(comm.handle)
+        if gave_up == 0:
+            pytest.skip("the exchange landed before the edge bands asked for their halo row on this box")
+        with pytest.raises(pkg.GrayHipError) as ei:
+            step()
+        assert "gave up" in str(ei.value)
+        comm.set_step_form(1)                                  # the serial form: unaffected, and the choice acknowledges the count
+        assert pkg.abi.load().gh_comm_halo_timeouts(comm.handle) == 0
+        buf[0] = 0x11
+        buf[h + 1] = 0x22
+        step()
+        t.cuda.synchronize()
+        assert t.equal(edge, want)
+        comm.set_step_form(-1)
+        edge.zero_()
+        step()
+        t.cuda.synchronize()
+        assert t.equal(edge, want) and pkg.abi.load().gh_comm_halo_timeouts(comm.handle) == 0
+    finally:
+        comm.close()
+
+
 def test_step_form_is_selectable_per_communicator(pkg, oracle, native_comm, torch_mod):
     """gh_comm_set_step_form: the form of the single-frame steps without touching the environment (bench.py falls back from the
     halo-flag form to the serial one this way); all three give the same pixels, the counter sees one exchange per step."""
