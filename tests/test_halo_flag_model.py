@@ -145,3 +145,115 @@ def test_the_model_catches_a_broken_protocol():
         except AssertionError:
             broken += 1
     assert broken > 30, "a side stream that does not wait for `started` went unnoticed"
+
+
+# ---- the stream step (gh_sharded_*_stream_step_dev): the halo rows of frame k + 1 travel beside the launch on frame k ---------------
+
+def _run_stream(n, frames, ring, seed):
+    """Frames 0 .. frames-1 cycle through `ring` buffers.  Caller's stream of a rank: P(0), then per step k: P(k + 1) (the next frame's
+    rows, into buffer (k + 1) % ring), K(k).  Side stream: per step k behind `started` >= k + 1: [the cold-start exchange of frame 0 at
+    k = 0,] the exchange of frame k + 1, each followed by the flag number of its frame.  K(k) may finish only behind the flag of frame k."""
+    rng = random.Random(seed)
+    R = [Rank(r, n, frames, rng) for r in range(n)]
+    for k in R:
+        k.main = [("P", 0)] + [x for j in range(frames) for x in ((("P", j + 1),) if j + 1 < frames else ()) + (("K", j),)]
+        k.side = []
+        for j in range(frames):
+            if j == 0:
+                k.side += [("W", 0), ("X", 0), ("F", 0)]
+            if j + 1 < frames:
+                k.side += [("W", j), ("X", j + 1), ("F", j + 1)]
+        k.buf_version = {}           # ring slot -> frame whose rows it holds
+        k.halo = {}                  # ring slot -> {"up": frame, "down": frame}
+        k.flag = -1
+        k.started = -1
+        k.x_posted, k.x_done, k.k_done = -1, -1, -1
+        k.reading = None             # ring slot the running kernel reads
+    now, guard = 0.0, 0
+    enq = lambda k, j: k.enq[min(max(j, 0), frames - 1)]
+    while any(k.mi < len(k.main) or k.si < len(k.side) or k.k_running for k in R):
+        guard += 1
+        assert guard < 400000, "no progress: deadlock"
+        progressed = False
+        for k in R:
+            has_nb = k.up is not None or k.down is not None
+            if k.k_running:
+                j, t_min = k.k_running
+                if now >= t_min and (not has_nb or k.flag >= j):
+                    slot = j % ring
+                    if k.up is not None:
+                        assert k.halo[slot]["up"] == j, (k.r, j, "stale upper halo", k.halo[slot])
+                    if k.down is not None:
+                        assert k.halo[slot]["down"] == j, (k.r, j, "stale lower halo", k.halo[slot])
+                    assert k.buf_version[slot] == j, (k.r, j, "the frame was overwritten under the kernel")
+                    k.k_running, k.k_done, k.reading = None, j, None
+                    progressed = True
+            elif k.mi < len(k.main) and now >= k.busy_until_main:
+                op, j = k.main[k.mi]
+                if now >= enq(k, j - 1 if op == "P" else j):
+                    if op == "P":
+                        slot = j % ring
+                        # the rows this overwrites were sent by the exchange of frame j - ring: it must have read them
+                        assert j - ring < 0 or not has_nb or k.x_done >= j - ring, (k.r, j, "producer overtook the exchange of the frame it replaces")
+                        k.buf_version[slot] = j
+                        k.busy_until_main = now + k.dur()
+                    else:
+                        k.started = j
+                        k.reading = j % ring
+                        k.k_running = (j, now + k.dur())
+                    k.mi += 1
+                    progressed = True
+            if k.si < len(k.side) and now >= k.busy_until_side:
+                op, j = k.side[k.si]
+                step_of = j if op == "W" else max(j - 1, 0)
+                if now >= enq(k, step_of):
+                    if op == "W":
+                        if k.started >= j:
+                            k.si += 1
+                            progressed = True
+                    elif op == "X":
+                        slot = j % ring
+                        if k.x_posted < j:
+                            assert k.buf_version.get(slot) == j, (k.r, j, "exchange read rows of frame %s" % k.buf_version.get(slot))
+                            assert k.reading != slot or k.k_running is None or k.k_running[0] == j, (k.r, j, "exchange overwrites halo rows a kernel still reads")
+                            k.sent[j] = j
+                            k.x_posted = j
+                            progressed = True
+                        nbs = [R[i] for i in (k.up, k.down) if i is not None]
+                        if all(nb.x_posted >= j for nb in nbs):
+                            k.halo[slot] = {"up": R[k.up].sent[j] if k.up is not None else None, "down": R[k.down].sent[j] if k.down is not None else None}
+                            k.x_done = j
+                            k.busy_until_side = now + k.dur()
+                            k.si += 1
+                            progressed = True
+                    else:
+                        k.flag = j
+                        k.si += 1
+                        progressed = True
+        if not progressed:
+            cands = [t for k in R for t in (k.busy_until_main, k.busy_until_side) if t > now]
+            cands += [k.k_running[1] for k in R if k.k_running and k.k_running[1] > now]
+            cands += [t for k in R for t in k.enq if t > now]
+            assert cands, "no progress and nothing pending: deadlock"
+            now = min(cands)
+    for k in R:
+        assert k.k_done == frames - 1
+
+
+@pytest.mark.parametrize("n,ring", [(2, 2), (3, 3), (8, 2), (8, 8), (4, 5)])
+def test_stream_step_handshake_is_deadlock_free_and_ordered(n, ring):
+    for seed in range(80):
+        _run_stream(n, frames=7, ring=ring, seed=seed * 13 + n + ring)
+
+
+def test_stream_step_needs_two_buffers_per_rank():
+    """With ONE buffer the next frame's rows would be written while the launch on the current frame still reads them: the real code
+    passes next = NULL for a ring of one and exchanges beside the launch instead; the model, forced to prefetch into the buffer in
+    use, must object."""
+    bad = 0
+    for seed in range(40):
+        try:
+            _run_stream(3, frames=5, ring=1, seed=seed)
+        except AssertionError:
+            bad += 1
+    assert bad > 30
