@@ -115,6 +115,66 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode        # stdout is inherited: rank 0 writes the JSON line to it
 
 
+class Watchdog:
+    """N > 1 only.  Every phase that talks to other ranks runs under a wall-clock budget: a peer that never answers leaves a rank inside
+    a collective or a device-side receive for good, and a run that is killed from outside leaves no line at all.  When a budget runs out
+    rank 0 writes the line with what it has -- `value` and the single-frame figures if they were measured, else `value: null` and the
+    reason -- and every rank ends its own process (each has its own watchdog and the same budgets, so they all go within seconds; the
+    in-kernel waits of libgrayhip are bounded by themselves, GH_HALO_WAIT_MS).  Exit code 0 when `value` and its checks were good."""
+
+    def __init__(self, json_fd: int, rank: int, minimal: dict):
+        import threading
+        self.json_fd, self.rank, self.partial, self.good = json_fd, rank, dict(minimal), False
+        self.lock = threading.Lock()
+        self.deadline, self.phase, self.budget, self.done = None, "", 0.0, False
+        self.spent = {}
+        self._t0 = None
+        self.written = False
+        t = threading.Thread(target=self._loop, daemon=True)
+        t.start()
+
+    def arm(self, phase: str, seconds: float):
+        with self.lock:
+            self.phase, self.budget, self.deadline, self._t0 = phase, seconds, time.monotonic() + seconds, time.monotonic()
+
+    def disarm(self):
+        with self.lock:
+            if self._t0 is not None:
+                self.spent[self.phase] = round(self.spent.get(self.phase, 0.0) + time.monotonic() - self._t0, 2)
+            self.deadline, self._t0 = None, None
+
+    def finish(self):
+        with self.lock:
+            self.done, self.deadline = True, None
+
+    def line_written(self):
+        """Rank 0 has written the complete line: a later budget (shutdown) ends the process without writing anything."""
+        with self.lock:
+            self.written = True
+
+    def _loop(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                if self.done:
+                    return
+                if self.deadline is None or time.monotonic() < self.deadline:
+                    continue
+                msg = f"{self.phase} exceeded its wall-clock budget of {self.budget:.0f} s on rank {self.rank}"
+                print(f"bench.py: watchdog: {msg}; writing what has been measured and ending the process", file=sys.stderr, flush=True)
+                if self.rank == 0 and not self.written:
+                    line = dict(self.partial)
+                    line["watchdog"] = msg
+                    line["wall_clock_s"] = dict(self.spent)
+                    if line.get("value") is None:
+                        line["error"] = msg
+                    try:
+                        os.write(self.json_fd, (json.dumps(line, default=str) + "\n").encode())
+                    except Exception:
+                        pass
+                os._exit(0 if self.good else 5)
+
+
 # ---- synthetic frames: SURVEY.md section 8(c) rand(seed), i.e. the SplitMix64 output stream, generated ON the GPU -------
 
 def _s64(v: int) -> int:
@@ -409,6 +469,29 @@ def main() -> int:
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    METRIC = "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel"
+    wd = None
+    budget_scale = float(os.environ.get("GH_BENCH_BUDGET_SCALE", "1"))
+    if world > 1:
+        wd = Watchdog(json_fd, rank, {"metric": METRIC, "value": None, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                      "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
+                                      "data": "synthetic"})
+
+    class phase:
+        """`with phase(name, seconds):` -- the block runs under the watchdog's wall-clock budget (N > 1; a no-op on one GPU)"""
+
+        def __init__(self, name, seconds):
+            self.name, self.seconds = name, seconds * budget_scale
+
+        def __enter__(self):
+            if wd is not None:
+                wd.arm(self.name, self.seconds)
+
+        def __exit__(self, *exc):
+            if wd is not None:
+                wd.disarm()
+            return False
+
     pkg = importlib.import_module("openmp-parallel-computing_amd")
     api, sharding = pkg.hostapi, pkg.sharding
     api.init(local_rank)
@@ -494,23 +577,26 @@ def main() -> int:
     if world > 1:
         exchange = "torch.distributed P2P (batch_isend_irecv over RCCL)"
         if args.exchange == "native":
-            try:
-                if rehearsal_loopback:
-                    native = sharding.NativeHaloComm(0, 1)
-                    native.set_loopback(True)
-                else:
-                    native = sharding.NativeHaloComm(rank, world)
-            except Exception as exc:
-                exchange_note = f"native communicator unavailable on rank {rank}: {exc}"
-            if native is not None:
-                comms_to_close.append(native)
-            if not all_ranks_agree(native is not None):
-                native = None
-            if native is not None:
-                one = torch.ones(1, dtype=torch.int64, device=device)
-                native.allreduce_sum_u64(one, stream.cuda_stream)
-                torch.cuda.synchronize()
-                rccl_ranks = int(one.item())
+            with phase("libgrayhip communicator setup (ncclCommInitRank + neighbour warm-up + one all-reduce)", 240):
+                try:
+                    if rehearsal_loopback:
+                        # every rank drives the native step with a private one-rank communicator, as the kind of shard it is in the job:
+                        # rank 0 the top shard (frame border above, one halo row), the last rank the bottom shard, the others middle shards
+                        native = sharding.NativeHaloComm(0, 1)
+                        native.set_loopback(native.LOOPBACK_TOP if rank == 0 else (native.LOOPBACK_BOTTOM if rank == world - 1 else native.LOOPBACK_MIDDLE))
+                    else:
+                        native = sharding.NativeHaloComm(rank, world)
+                except Exception as exc:
+                    exchange_note = f"native communicator unavailable on rank {rank}: {exc}"
+                if native is not None:
+                    comms_to_close.append(native)
+                if not all_ranks_agree(native is not None):
+                    native = None
+                if native is not None:
+                    one = torch.ones(1, dtype=torch.int64, device=device)
+                    native.allreduce_sum_u64(one, stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    rccl_ranks = int(one.item())
             # the line must never quietly time torch P2P when libgrayhip's communicator was asked for: on real ranks that is a failure
             if not rehearsal and (native is None or rccl_ranks != world):
                 msg = f"libgrayhip's RCCL communicator met {rccl_ranks} of {world} ranks" if native is not None else \
@@ -518,9 +604,11 @@ def main() -> int:
                 print(f"bench.py: {msg}; refusing to time the torch.distributed fallback in its place (--exchange torch asks for it explicitly)",
                       file=sys.stderr)
                 if rank == 0:
-                    os.write(json_fd, (json.dumps({"metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel", "value": None, "unit": "Mpixels/s",
+                    os.write(json_fd, (json.dumps({"metric": METRIC, "value": None, "unit": "Mpixels/s",
                                                    "n_gpus": world, "error": msg, "ranks": ranks_met, "rccl_ranks": rccl_ranks,
                                                    "exchange_fallback": True}) + "\n").encode())
+                if wd is not None:
+                    wd.finish()
                 dist.barrier()
                 for comm in comms_to_close:
                     try:
@@ -534,6 +622,8 @@ def main() -> int:
     # N = 1: one frame, rand(seed=1).  N > 1: a ring of eight frames, rand(seed = 1 .. 8) (a stream of frames, step k works
     # on frame k % 8), so that the halo rows of later frames can be exchanged while the current one is processed -- four frames
     # per exchange in the batched form -- and so that the ring (8 x 100 MB per rank at N = 8) cannot live in the 256 MB Infinity Cache.
+    if wd is not None:
+        wd.arm("synthetic frames and shard runners", 240 * budget_scale)
     NBUF = 1 if single else 8
     BATCH = 4
     row_bytes = W * 3
@@ -558,6 +648,8 @@ def main() -> int:
             r = sharding.ShardedGraySobel(geom, backend, device, overlap=overlap)
             rgbs.append(frame)
         runners.append(r)
+    if wd is not None:
+        wd.disarm()
     rgb = rgbs[0]
     halo_bufs = ([r.rgb for r in runners] if fused else [r.luma for r in runners]) if not single else []   # (rows+2)-row buffers
     KA = known_answers()
@@ -567,6 +659,7 @@ def main() -> int:
     out = {}
     check = "skipped"
     halo_ok = True
+    halo_rows_note = None
 
     if single:
         # ================================ one GPU =========================================================================
@@ -765,6 +858,7 @@ def main() -> int:
         single_impl, single_edge = (lambda k: torch_step(0)), runners[0].edge
         stream_impl = torch_step          # a stream of DIFFERENT frames, each step the whole single-frame step on the next one
         batched_impl = None               # (native only) the same stream with the halo rows of four future frames per exchange
+        wd.arm("validation of libgrayhip's sharded steps against torch.distributed on the first frames", 300 * budget_scale)
         if native is not None:
             # libgrayhip issues the exchange itself: halo of frame k+2 beside the kernel(s) of frame k, one C call per step
             AHEAD = 2
@@ -817,7 +911,7 @@ def main() -> int:
                         for _ in range(3):
                             native_single(0)
                             torch.cuda.synchronize()
-                            good = good and bool(torch.equal(edge_native, runners[0].edge))
+                            good = good and bool(torch.equal(edge_native, runners[0].edge)) and native.halo_timeouts() == 0
                     except Exception as exc_:
                         print(f"bench.py: rank {rank}: single-frame step failed: {exc_}", file=sys.stderr)
                         good = False
@@ -859,6 +953,7 @@ def main() -> int:
                 exchange_note = exchange_note or "native exchange disagreed with torch.distributed on the first frames; using torch"
                 native = None
 
+        wd.disarm()
         calls = {}
 
         def with_events(impl, name):
@@ -883,29 +978,65 @@ def main() -> int:
         forms = {}
         xc0 = native.exchange_count() if native is not None else 0
         # (a) ONE frame, strong-scaled (BASELINE configs[3]): every step = one halo exchange + the shard -- `value`
-        forms["single_frame"], elapsed = run_form(single_impl, args.steps, "single_frame")
-        value = W * H_total * args.steps / elapsed / 1e6
-        step_ms_events = forms["single_frame"]["ms_per_step_events_rank0"]
-        rep_ms = [elapsed / args.steps * 1e3]
-        fn_single = with_events(single_impl, "single_frame_repeats")
-        for _ in range(max(args.repeats, 1) - 1):
-            el_r, _ = timed(fn_single, args.steps, None, None)
-            rep_ms.append(el_r / args.steps * 1e3)
-        if native is not None:
-            forms["single_frame"]["exchanges_per_step"] = round((native.exchange_count() - xc0) / max(calls["single_frame"] + calls["single_frame_repeats"], 1), 3)
-        # Sum of the edge plane over all ranks against the compiled reference's known answer (single-frame form, frame rand(seed=1))
-        edge_sum_check = "skipped"
-        if not args.no_check and not rehearsal_loopback:
-            tsum = single_edge.sum(dtype=torch.int64).reshape(1)
-            if rehearsal:
-                tsum = tsum.cpu()
-            dist.all_reduce(tsum)
-            if is_known_frame and KA and args.scaling == "strong" and ka_mode == "IEEE":
-                want = int(KA["IEEE"]["rand1_16384"]["edge_sum"])
-                edge_sum_check = "ok: sum of the sharded edge plane == compiled reference" if int(tsum.item()) == want else \
-                    f"MISMATCH ({int(tsum.item())} != {want})"
-            else:
-                edge_sum_check = f"unpinned geometry (sum {int(tsum.item())})"
+        with phase("single_frame (value)", 180):
+            t_form = time.perf_counter()
+            forms["single_frame"], elapsed = run_form(single_impl, args.steps, "single_frame")
+            value = W * H_total * args.steps / elapsed / 1e6
+            step_ms_events = forms["single_frame"]["ms_per_step_events_rank0"]
+            rep_ms = [elapsed / args.steps * 1e3]
+            fn_single = with_events(single_impl, "single_frame_repeats")
+            for _ in range(max(args.repeats, 1) - 1):
+                el_r, _ = timed(fn_single, args.steps, None, None)
+                rep_ms.append(el_r / args.steps * 1e3)
+            if native is not None:
+                forms["single_frame"]["exchanges_per_step"] = round((native.exchange_count() - xc0) / max(calls["single_frame"] + calls["single_frame_repeats"], 1), 3)
+            forms["single_frame"]["wall_s"] = round(time.perf_counter() - t_form, 2)
+            # Sum of the edge plane over all ranks against the compiled reference's known answer (single-frame form, frame rand(seed=1))
+            edge_sum_check = "skipped"
+            if not args.no_check and not rehearsal_loopback:
+                tsum = single_edge.sum(dtype=torch.int64).reshape(1)
+                if rehearsal:
+                    tsum = tsum.cpu()
+                dist.all_reduce(tsum)
+                if is_known_frame and KA and args.scaling == "strong" and ka_mode == "IEEE":
+                    want = int(KA["IEEE"]["rand1_16384"]["edge_sum"])
+                    edge_sum_check = "ok: sum of the sharded edge plane == compiled reference" if int(tsum.item()) == want else \
+                        f"MISMATCH ({int(tsum.item())} != {want})"
+                else:
+                    edge_sum_check = f"unpinned geometry (sum {int(tsum.item())})"
+            halo_timeouts = native.halo_timeouts() if native is not None else 0
+            timeouts_ok = all_ranks_agree(halo_timeouts == 0)
+        # From here on `value` exists: whatever happens to the optional forms below, the line is written with it (the watchdog holds a copy).
+        value_good = not edge_sum_check.startswith("MISMATCH") and timeouts_ok
+        if wd is not None:
+            wd.partial.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "step_forms": forms,
+                               "edge_sum_check": edge_sum_check, "halo_flag_timeouts": halo_timeouts,
+                               "config": {"workload": f"{W}x{H_total} RGB8 frame rand(seed=1) row-sharded x{world} (BASELINE configs[3]), pipeline={args.pipeline}, mode={args.mode}"},
+                               "incomplete": "the optional step forms did not all finish"})
+            wd.good = value_good
+
+        inject = os.environ.get("GH_BENCH_INJECT", "")
+
+        def guarded(name, seconds, body):
+            """An optional figure: a failure -- on any rank -- lands in the line as <name>.error instead of costing the run its `value`."""
+            t0_ = time.perf_counter()
+            res, err = None, None
+            with phase(name, seconds):
+                try:
+                    if inject == f"fail:{name}":               # (tests: a form that throws / never returns must not cost the line)
+                        raise RuntimeError("failure injected by GH_BENCH_INJECT")
+                    if inject == f"hang:{name}":
+                        time.sleep(1e6)
+                    res = body()
+                except Exception as exc:
+                    err = f"{type(exc).__name__}: {exc}"
+                    print(f"bench.py: rank {rank}: {name} failed: {err}", file=sys.stderr)
+                everyone = all_ranks_agree(err is None)
+            if not everyone:
+                res = {"error": err or "failed on another rank"}
+            if isinstance(res, dict):
+                res["wall_s"] = round(time.perf_counter() - t0_, 2)
+            return res
 
         # Per-rank breakdown of the single-frame step (HIP events on every rank, same K everywhere): the shard kernel alone (no
         # exchange), the exchange alone (nothing beside it), the whole step.  step - kernel = what the exchange costs on top of the
@@ -922,8 +1053,7 @@ def main() -> int:
             fence()
             return a_.elapsed_time(b_) / k_steps * 1e3           # us
 
-        breakdown = None
-        try:
+        def breakdown_body():
             kb = max(args.steps, 20)
             hb0 = halo_bufs[0]
             if fused:
@@ -951,55 +1081,46 @@ def main() -> int:
             else:
                 dist.all_gather(allr, mine)
             rows_ = [[round(float(v), 1) for v in t_.tolist()] for t_ in allr]
-            breakdown = {"unit": "us per step, HIP events on each rank's stream", "steps": kb,
-                         "shard_kernel_alone": [r_[0] for r_ in rows_],
-                         "exchange_alone": [r_[1] if r_[1] >= 0 else None for r_ in rows_],
-                         "single_frame_step": [r_[2] for r_ in rows_],
-                         "exchange_not_hidden": [round(r_[2] - r_[0], 1) for r_ in rows_],
-                         "note": "step - kernel = what the halo exchange costs after overlap; exchange_alone is the unloaded RCCL group "
-                                 "(beside a bandwidth-bound kernel the same group takes ~3x as long: DESIGN.md section 6)"}
-        except Exception as exc:
-            breakdown = {"error": f"{type(exc).__name__}: {exc}"}
+            return {"unit": "us per step, HIP events on each rank's stream", "steps": kb,
+                    "shard_kernel_alone": [r_[0] for r_ in rows_],
+                    "exchange_alone": [r_[1] if r_[1] >= 0 else None for r_ in rows_],
+                    "single_frame_step": [r_[2] for r_ in rows_],
+                    "exchange_not_hidden": [round(r_[2] - r_[0], 1) for r_ in rows_],
+                    "note": "step - kernel = what the halo exchange costs after overlap (rank 0 and the last rank wait for ONE halo row and keep the frame's "
+                            "zero border on the other side); exchange_alone is the unloaded RCCL group (beside a bandwidth-bound kernel the same group "
+                            "takes ~3x as long: DESIGN.md section 6)"}
 
-        # (b) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
-        host_shard = torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True)
-        host_shard.copy_(rgbs[0])
-        torch.cuda.synchronize()
+        breakdown = guarded("per_rank breakdown", 120, breakdown_body)
 
-        def e2e_impl(k):
-            rgbs[0].copy_(host_shard, non_blocking=True)
-            single_impl(k)
-        k_e2e = max(1, min(args.steps, 20))
-        forms["end_to_end_h2d"], _ = run_form(e2e_impl, k_e2e, "end_to_end_h2d")
-        # (c) a stream of DIFFERENT frames (ring of eight), every step the whole single-frame step -- its own exchange and its own launch --
-        # on the next frame: what `value` becomes when no frame is seen twice (nothing of it can sit in the 256 MB Infinity Cache)
-        forms["stream_of_frames"], _ = run_form(stream_impl, args.steps, "stream_of_frames")
-        # (d) the same stream with the halo rows of four future frames per exchange (events; round 2's form): fewer, larger exchanges
-        if batched_impl is not None:
-            xc1 = native.exchange_count()
-            forms["pipelined_batched"], _ = run_form(batched_impl, args.steps, "pipelined_batched")
-            forms["pipelined_batched"]["exchanges_per_step"] = round((native.exchange_count() - xc1) / max(calls["pipelined_batched"], 1), 3)
-        # (e) the same stream software-pipelined: the halo rows of the next frame travel beside this frame's launch
-        xc1 = native.exchange_count() if native is not None else 0
-        forms["pipelined"], _ = run_form(pipelined_impl, args.steps, "pipelined")
+        # every rank's halo rows must hold its neighbours' edge rows: one more single-frame step on frame 0, then what its exchange delivered
+        def halo_rows_body():
+            good = True
+            single_impl(0)
+            torch.cuda.synchronize()
+            lrgb, hbuf = rgbs[0], halo_bufs[0]
+            firsts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+            lasts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+            if rehearsal:
+                firsts, lasts = [t_.cpu() for t_ in firsts], [t_.cpu() for t_ in lasts]
+                dist.all_gather(firsts, lrgb[0].contiguous().cpu())
+                dist.all_gather(lasts, lrgb[rows - 1].contiguous().cpu())
+                firsts, lasts = [t_.to(device) for t_ in firsts], [t_.to(device) for t_ in lasts]
+            else:
+                dist.all_gather(firsts, lrgb[0].contiguous())
+                dist.all_gather(lasts, lrgb[rows - 1].contiguous())
+            up_row, down_row = hbuf[0], hbuf[rows + 1]
+            conv = (lambda t: t) if fused else (lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W))
+            if rank > 0:
+                good &= bool(torch.equal(up_row, conv(lasts[rank - 1])))
+            if rank < world - 1:
+                good &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
+            return {"ok": bool(good or rehearsal_loopback)}
+
+        hr = guarded("halo rows check", 90, halo_rows_body)
+        halo_ok = all_ranks_agree(bool(hr.get("ok", False)) or "error" in hr) if isinstance(hr, dict) else False
+        halo_rows_note = hr.get("error") if isinstance(hr, dict) else None
         if native is not None:
-            forms["pipelined"]["exchanges_per_step"] = round((native.exchange_count() - xc1) / max(calls["pipelined"], 1), 3)
-
-        # every rank's halo rows must hold its neighbours' edge rows (what the last pipelined step's exchange delivered)
-        last = calls["pipelined"] - 1
-        lrgb, ledge, hbuf = rgbs[last % NBUF], edge_of(last), halo_bufs[last % NBUF]
-        firsts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
-        lasts = [torch.empty((W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(firsts, lrgb[0].contiguous())
-        dist.all_gather(lasts, lrgb[rows - 1].contiguous())
-        up_row, down_row = hbuf[0], hbuf[rows + 1]
-        conv = (lambda t: t) if fused else (lambda t: api.gray_to_plane(t.reshape(1, W, 3).contiguous(), mode).reshape(W))
-        if rank > 0:
-            halo_ok &= bool(torch.equal(up_row, conv(lasts[rank - 1])))
-        if rank < world - 1:
-            halo_ok &= bool(torch.equal(down_row, conv(firsts[rank + 1])))
-        halo_ok = all_ranks_agree(halo_ok or rehearsal_loopback)
-        halo_timeouts = int(lib.gh_comm_halo_timeouts(native.handle)) if native is not None else 0
+            halo_timeouts = native.halo_timeouts()
         if not all_ranks_agree(halo_timeouts == 0):
             halo_ok = False
 
@@ -1007,6 +1128,7 @@ def main() -> int:
             try:
                 import numpy as np
                 from oracle import pyoracle as O          # checker only
+                lrgb, ledge, hbuf = rgbs[0], single_edge, halo_bufs[0]
                 r = min(rows, 96)
                 want = O.sobel(O.gray_to_plane(lrgb[0:r + 1].cpu().numpy(), mode))[: r - 1]
                 got = ledge[: r - 1].cpu().numpy()
@@ -1016,14 +1138,53 @@ def main() -> int:
                     src = hbuf[rows - 30:rows + 2].cpu().numpy()                # buffer rows = shard rows rows-31 .. rows-1 + the halo row
                     want = O.sobel(O.gray_to_plane(src, mode))[1:-1]             # shard rows rows-30 .. rows-1
                     good = good and np.array_equal(ledge[rows - 30:rows].cpu().numpy(), want)
-                check = "ok (rank 0: first rows and the rows behind the received halo vs oracle)" if good else "MISMATCH"
+                check = "ok (rank 0, single-frame step: first rows and the rows behind the received halo vs oracle)" if good else "MISMATCH"
             except Exception as exc:  # the checker is optional on the GPU box; a mismatch is never hidden
                 check = f"unavailable ({type(exc).__name__})"
         bad = check == "MISMATCH" or not halo_ok or edge_sum_check.startswith("MISMATCH")
+        if all_ranks_agree(not bad) is False:
+            bad = True
         if bad:
             print(f"bench.py: parity check FAILED (check={check}, halo rows ok={halo_ok}, halo-flag timeouts={halo_timeouts}, edge sum: {edge_sum_check})",
                   file=sys.stderr)
+            if wd is not None:
+                wd.finish()
             return 3
+
+        # ---- the optional forms, each guarded: a failure costs its own figure only ----------------------------------------------------
+        def form_body(impl, k_steps, name, count_exchanges=False):
+            def body():
+                x0 = native.exchange_count() if (native is not None and count_exchanges) else 0
+                res, _ = run_form(impl, k_steps, name)
+                if native is not None and count_exchanges:
+                    res["exchanges_per_step"] = round((native.exchange_count() - x0) / max(calls[name], 1), 3)
+                if native is not None:
+                    native.check()                                  # (behind run_form's final synchronisation)
+                return res
+            return body
+
+        # (b) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
+        def e2e_body():
+            host_shard = torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True)
+            host_shard.copy_(rgbs[0])
+            torch.cuda.synchronize()
+
+            def e2e_impl(k):
+                rgbs[0].copy_(host_shard, non_blocking=True)
+                single_impl(k)
+            return form_body(e2e_impl, max(1, min(args.steps, 20)), "end_to_end_h2d")()
+
+        forms["end_to_end_h2d"] = guarded("end_to_end_h2d", 120, e2e_body)
+        # (c) a stream of DIFFERENT frames (ring of eight), every step the whole single-frame step -- its own exchange and its own launch --
+        # on the next frame: what `value` becomes when no frame is seen twice (nothing of it can sit in the 256 MB Infinity Cache)
+        forms["stream_of_frames"] = guarded("stream_of_frames", 120, form_body(stream_impl, args.steps, "stream_of_frames"))
+        # (d) the same stream with the halo rows of four future frames per exchange (events; round 2's form): fewer, larger exchanges
+        if batched_impl is not None:
+            forms["pipelined_batched"] = guarded("pipelined_batched", 120, form_body(batched_impl, args.steps, "pipelined_batched", True))
+        # (e) the same stream software-pipelined: the halo rows of the next frame travel beside this frame's launch
+        forms["pipelined"] = guarded("pipelined", 120, form_body(pipelined_impl, args.steps, "pipelined", True))
+        if native is not None:
+            halo_timeouts = native.halo_timeouts()
 
         bpp = 4 if fused else 6
         a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
@@ -1032,9 +1193,10 @@ def main() -> int:
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
                     "traffic_source": "not recorded for shards (the 1-GPU line carries the PMC figure of the same kernel)"}
         out.update({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "roofline": roofline,
-                    "step_single_frame_ms": forms["single_frame"]["ms_per_step"], "step_pipelined_ms": forms["pipelined"]["ms_per_step"],
-                    "step_end_to_end_ms": forms["end_to_end_h2d"]["ms_per_step"], "step_stream_of_frames_ms": forms["stream_of_frames"]["ms_per_step"],
+                    "step_single_frame_ms": forms["single_frame"]["ms_per_step"], "step_pipelined_ms": forms["pipelined"].get("ms_per_step"),
+                    "step_end_to_end_ms": forms["end_to_end_h2d"].get("ms_per_step"), "step_stream_of_frames_ms": forms["stream_of_frames"].get("ms_per_step"),
                     "step_forms": forms,
+                    "wall_clock_s": dict(wd.spent) if wd is not None else None,
                     "working_set_note": (f"per GPU the step touches {px_rank * 4 / 1e6:.0f} MB (shard in, edge plane out); the single-frame form re-reads ONE shard, of which a "
                                          "256 MB Infinity Cache can keep a part once that is small enough (N >= 4 for this frame) -- stream_of_frames is the same step "
                                          "on eight different frames, where nothing is seen twice"),
@@ -1053,7 +1215,7 @@ def main() -> int:
 
     if rank == 0:
         final = {
-            "metric": "Mpixels/s, 16384x16384 RGB8 grayscale+Sobel",
+            "metric": METRIC,
             "value": out.pop("value"),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -1078,7 +1240,8 @@ def main() -> int:
             "exchange_fallback": False,
         }
         final.update(out)
-        final.update({"parity_check": check, "halo_rows_check": "ok" if halo_ok else "MISMATCH", "settle_ms": args.settle_ms})
+        final.update({"parity_check": check, "halo_rows_check": ("ok" if halo_ok else "MISMATCH") if world == 1 or not halo_rows_note else f"not run ({halo_rows_note})",
+                      "settle_ms": args.settle_ms})
         if rehearsal:
             final["rehearsal"] = "ranks share one GPU over gloo: code-path rehearsal only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
@@ -1088,9 +1251,12 @@ def main() -> int:
                 final["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "unavailable",
                                          "sample": f"{type(exc).__name__}: {exc}"}
         sys.stdout.flush()
+        if wd is not None:
+            wd.line_written()          # (the line is complete: the watchdog must not write a second one)
         os.write(json_fd, (json.dumps(final) + "\n").encode())
 
     if world > 1:
+        wd.arm("shutdown (barrier, communicator and process-group teardown)", 120 * budget_scale)
         torch.cuda.synchronize()
         dist.barrier()
         for comm in comms_to_close:        # every rank has finished with the communicator: release it before the process group
@@ -1099,6 +1265,7 @@ def main() -> int:
             except Exception:
                 pass
         dist.destroy_process_group()
+        wd.finish()
     return 0
 
 

@@ -178,9 +178,12 @@ GH_API int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world,
 GH_API int gh_comm_rank(gh_comm_t comm);
 GH_API int gh_comm_world(gh_comm_t comm);
 GH_API int gh_comm_destroy(gh_comm_t comm);
-/* rehearsal hook for a one-GPU box: the sharded steps below treat this rank as a MIDDLE shard whose two neighbours
- * are itself (ncclSend/ncclRecv to self), i.e. the halo rows become copies of the shard's own first / last row */
-GH_API int gh_comm_set_loopback(gh_comm_t comm, int on);
+/* rehearsal hook for a one-GPU box: the sharded steps below treat this rank as one of the three kinds of shard a multi-GPU job has,
+ * with ncclSend/ncclRecv to ITSELF standing in for the neighbours (a halo row becomes a copy of the shard's own first / last row):
+ *   mode 1  a MIDDLE shard: neighbours above and below;
+ *   mode 2  the TOP shard (rank 0 of N): the frame's zero border above (monolithic/src/sobel.c:11-12), ONE halo row, from below;
+ *   mode 3  the BOTTOM shard (rank N-1): the mirror image;      mode 0: off. */
+GH_API int gh_comm_set_loopback(gh_comm_t comm, int mode);
 /* one ncclGroup on `stream`: send_up -> up_peer and its row -> recv_up; same downwards; peer < 0 = frame border */
 GH_API int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void *recv_up, int down_peer,
                                 const void *send_down, void *recv_down, size_t bytes, gh_stream_t stream);
@@ -196,6 +199,13 @@ GH_API unsigned long long gh_comm_exchange_count(gh_comm_t comm);
  * GH_HALO_WAIT_MS (default 10000) beside a launch whose edge bands were waiting for it; that step's edge rows are invalid and every
  * later halo-flag step on this communicator fails until gh_comm_set_step_form acknowledges it (the serial and event forms keep working). */
 GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
+/* The check that belongs behind the synchronisation which hands a sharded step's output to the host (the steps are asynchronous, a wait
+ * that gives up is only known once the launch has run): GH_OK, or GH_ERR_HIP when gh_comm_halo_timeouts() is non-zero -- the output of
+ * that step must not be used.  Reads host-mapped memory; costs nothing.  Callers of the sharded steps through this C API call it after
+ * their hipStreamSynchronize / gh_stream_sync (the Python runners' result() does). */
+GH_API int gh_comm_check(gh_comm_t comm);
+/* Bound of the halo-flag form's device-side waits on this communicator in milliseconds (default: GH_HALO_WAIT_MS, else 10000); -1 = default */
+GH_API int gh_comm_set_halo_wait_ms(gh_comm_t comm, int ms);
 /* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default (GH_SHARD_STEP_FORM=2, shards
  * that run an LDS-DMA ring kernel: 1024 columns and more): the one-row exchange runs on the communicator's side stream BESIDE one launch
  * over the whole shard on `stream`; only the workgroups of the first / last band wait -- inside the kernel -- for a flag set behind the

@@ -22,6 +22,7 @@ namespace {
 
 // the slice of the RCCL API used here (rccl.h: ncclGetUniqueId / ncclCommInitRank / ncclSend / ncclRecv / ...)
 constexpr int kIdBytes = 128;
+constexpr size_t kFlagBytes = 512;       // flag (dword 0), trace stamps (bytes 64..127), started (dword 32), warm-up rows (bytes 256..511)
 struct NcclId { char internal[kIdBytes]; };
 using nccl_comm_t = void *;
 enum { kNcclUint8 = 1, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
@@ -88,7 +89,12 @@ struct Comm {
     int rank = 0, world = 1;
     hipStream_t side = nullptr;          // the exchange runs here, beside the interior rows on the caller's stream
     hipEvent_t ready = nullptr, landed = nullptr;
-    bool loopback = false;               // rehearsal on one GPU: both neighbours are this rank (ncclSend/ncclRecv to self)
+    int loopback = 0;                    // rehearsal on one GPU (gh_comm_set_loopback): 1 = a middle shard whose two neighbours are this rank
+                                         // (ncclSend/ncclRecv to self), 2 = the TOP shard (frame border above, itself below), 3 = the BOTTOM shard
+    bool prio_ok = true;                 // the caller's stream last seen does not share the side stream's priority (halo-flag form, see sharded_step)
+    hipStream_t prio_stream = nullptr;
+    bool prio_seen = false;
+    int side_prio = 0;
     // pipelined steps: buffers whose halo rows the side stream has already been asked to fill, and the event that says
     // they have landed.  Requests come one buffer at a time (a halo two or three frames ahead) or as a BATCH -- the halos of
     // several future frames in one ncclGroup, one event for all of them (gh_sharded_prefetch_halos_dev): a pool of kPrefetch
@@ -115,7 +121,24 @@ struct Comm {
     const void *stream_buf = nullptr;
     uint32_t stream_xepoch = 0;
     int step_form = -1;                  // gh_comm_set_step_form: -1 = GH_SHARD_STEP_FORM / the default
+    int halo_wait_ms = -1;               // gh_comm_set_halo_wait_ms: -1 = GH_HALO_WAIT_MS / the default (10 s)
 };
+
+// The stream-of-frames step remembers which buffer's halo rows the previous call sent on their way (stream_buf / stream_xepoch).  Anything
+// else that touches halo rows or changes how a step runs -- a single-frame step, a direct exchange, a change of form or of the loopback
+// mode -- makes that memory stale: a later stream step on the same address would skip its exchange and wait for an epoch that has
+// already passed.  Such calls forget the announcement; the next stream step then exchanges `cur` beside its own launch.
+void forget_announced(Comm *c) { c->stream_buf = nullptr; }
+
+// the two neighbours of this rank's shard: rank -/+ 1, -1 = the frame border; the loopback modes stand in for the three kinds of shard
+void neighbours(const Comm *c, int &up, int &down)
+{
+    up = c->rank > 0 ? c->rank - 1 : -1;
+    down = c->rank + 1 < c->world ? c->rank + 1 : -1;
+    if (c->loopback == 1) up = down = c->rank;                   // middle shard: halo rows = its own first / last row
+    else if (c->loopback == 2) { up = -1; down = c->rank; }      // top shard: zero border above, waits for ONE halo row (below)
+    else if (c->loopback == 3) { up = c->rank; down = -1; }      // bottom shard: the mirror image
+}
 
 __global__ void k_set_halo_flag(uint32_t *flag, uint32_t epoch)
 {
@@ -167,7 +190,7 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
     Comm *c = new Comm;
     c->rank = rank;
     c->world = world;
-    c->epoch = c->xepoch = (uint32_t)GH_TUNE_INT("GH_HALO_EPOCH_START", 0);      // (tests start near the wrap guard of the halo-flag form)
+    c->epoch = c->xepoch = (uint32_t)GH_LAB_INT("GH_HALO_EPOCH_START", 0);      // (probe builds: tests start near the wrap guard of the halo-flag form)
     NcclId nid;
     memcpy(nid.internal, id, kIdBytes);
     const int r = g_rccl.CommInitRank(&c->nccl, world, nid, rank);
@@ -181,11 +204,12 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         int prio_least = 0, prio_greatest = 0;
         GH_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         GH_HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest));
+        c->side_prio = prio_greatest;
         GH_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
         GH_HIP_TRY(hipEventCreateWithFlags(&c->landed, hipEventDisableTiming));
         for (int i = 0; i < Comm::kPrefetch; ++i) GH_HIP_TRY(hipEventCreateWithFlags(&c->pf_landed[i], hipEventDisableTiming));
-        GH_HIP_TRY(hipMalloc((void **)&c->flag_dev, 256));
-        GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
+        GH_HIP_TRY(hipMalloc((void **)&c->flag_dev, kFlagBytes));
+        GH_HIP_TRY(hipMemset(c->flag_dev, 0, kFlagBytes));
         int can_wait = 0, dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can_wait &&
@@ -198,6 +222,17 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         GH_HIP_TRY(hipHostMalloc((void **)&c->timeouts_host, 64, hipHostMallocMapped));
         memset(c->timeouts_host, 0, 64);
         GH_HIP_TRY(hipHostGetDevicePointer((void **)&c->timeouts_dev, c->timeouts_host, 0));
+        // Peer connections now, not inside the first step: RCCL connects to a peer lazily, inside the first ncclGroupEnd that names it, and that
+        // can take seconds and block the host.  The halo-flag form queues a wait for `started` on the side stream BEFORE its exchange and bounds
+        // every device-side wait (GH_HALO_WAIT_MS), so a first exchange that connected under such a wait could be taken for a lost one.  One
+        // 64-byte row to and from each neighbour here (gh_comm_init is collective: every rank is in this call), then the connections exist.
+        if (world > 1) {
+            uint8_t *w = reinterpret_cast<uint8_t *>(c->flag_dev) + 256;
+            const int up = rank > 0 ? rank - 1 : -1, down = rank + 1 < world ? rank + 1 : -1;
+            if (int rc2 = gh_halo_exchange_dev(c, up, w, w + 64, down, w + 128, w + 192, 64, c->side)) return rc2;
+            GH_HIP_TRY(hipStreamSynchronize(c->side));
+            c->exchanges = 0;
+        }
         return GH_OK;
     }();
     if (rc != GH_OK) {
@@ -211,10 +246,13 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
 int gh_comm_rank(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->rank : -1; }
 int gh_comm_world(gh_comm_t comm) { return comm ? static_cast<Comm *>(comm)->world : -1; }
 
-int gh_comm_set_loopback(gh_comm_t comm, int on)
+int gh_comm_set_loopback(gh_comm_t comm, int mode)
 {
     GH_REQUIRE(comm, "null communicator");
-    static_cast<Comm *>(comm)->loopback = on != 0;
+    GH_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (off), 1 (middle shard), 2 (top shard) or 3 (bottom shard)");
+    Comm *c = static_cast<Comm *>(comm);
+    c->loopback = mode;
+    forget_announced(c);
     return GH_OK;
 }
 
@@ -227,7 +265,17 @@ int gh_comm_set_step_form(gh_comm_t comm, int form)
     GH_REQUIRE(form >= -1 && form <= 2, "form must be -1, 0, 1 or 2");
     Comm *c = static_cast<Comm *>(comm);
     c->step_form = form;
+    forget_announced(c);
     if (c->timeouts_host) __atomic_store_n(c->timeouts_host, 0u, __ATOMIC_RELEASE);      // choosing a form acknowledges waits that gave up earlier
+    return GH_OK;
+}
+
+// Bound of the device-side waits of the halo-flag form on this communicator, in milliseconds (-1: GH_HALO_WAIT_MS or the default, 10 s).
+int gh_comm_set_halo_wait_ms(gh_comm_t comm, int ms)
+{
+    GH_REQUIRE(comm, "null communicator");
+    GH_REQUIRE(ms >= -1, "ms must be >= 0, or -1 for the default");
+    static_cast<Comm *>(comm)->halo_wait_ms = ms;
     return GH_OK;
 }
 
@@ -257,6 +305,7 @@ int gh_halo_exchange_dev(gh_comm_t comm, int up_peer, const void *send_up, void 
     GH_REQUIRE(comm, "null communicator");
     Comm *c = static_cast<Comm *>(comm);
     GH_REQUIRE(up_peer < c->world && down_peer < c->world, "peer out of range");
+    forget_announced(c);       // (the stream step re-announces its `next` after its own exchanges)
     if (bytes == 0 || (up_peer < 0 && down_peer < 0)) return GH_OK;
     GH_REQUIRE((up_peer < 0 || (send_up && recv_up)) && (down_peer < 0 || (send_down && recv_down)), "null halo row");
     hipStream_t s = (hipStream_t)stream;
@@ -297,6 +346,18 @@ unsigned int gh_comm_halo_timeouts(gh_comm_t comm)
     return c->timeouts_host ? __atomic_load_n(c->timeouts_host, __ATOMIC_ACQUIRE) : 0;
 }
 
+// After the synchronisation that hands a sharded step's results to the host: did every halo-flag wait of the steps so far see its exchange?
+// (The count lives in host-mapped memory: no device call here.)
+int gh_comm_check(gh_comm_t comm)
+{
+    GH_REQUIRE(comm, "null communicator");
+    const unsigned int n = gh_comm_halo_timeouts(comm);
+    if (n)
+        return gh_set_error(GH_ERR_HIP, "%u halo-flag waits gave up after GH_HALO_WAIT_MS: a neighbour's rows did not arrive in time and the edge rows of "
+                                        "that sharded step are invalid (gh_comm_set_step_form acknowledges; form 1 waits like plain RCCL)", n);
+    return GH_OK;
+}
+
 int gh_comm_allreduce_sum_u64_dev(gh_comm_t comm, uint64_t *buf_dev, size_t count, gh_stream_t stream)
 {
     GH_REQUIRE(comm && buf_dev, "null pointer");
@@ -335,26 +396,46 @@ static int halo_flag_guard(Comm *c, hipStream_t s)
     if (c->epoch < 0x7ffffff0u && c->xepoch < 0x7ffffff0u) return GH_OK;
     GH_HIP_TRY(hipStreamSynchronize(s));
     GH_HIP_TRY(hipStreamSynchronize(c->side));
-    GH_HIP_TRY(hipMemset(c->flag_dev, 0, 256));
+    GH_HIP_TRY(hipMemset(c->flag_dev, 0, kFlagBytes));
     if (c->started_sig) GH_HIP_TRY(hipMemset(c->started_sig, 0, 8));
     c->epoch = c->xepoch = 0;
     c->stream_buf = nullptr;
     return GH_OK;
 }
 
+// The halo-flag form needs the caller's stream and the side stream on DIFFERENT hardware queues: the side stream's wait for `started` would
+// otherwise sit in front of the very launch that stores it.  The side stream has the greatest priority, which gives it a queue of its own
+// beside normal-priority streams; a caller that passes a stream of that same priority may share its queue -- such steps take the serial form.
+static bool caller_stream_ok(Comm *c, hipStream_t s)
+{
+    if (c->prio_seen && c->prio_stream == s) return c->prio_ok;
+    int prio = 0;
+    const bool known = s != nullptr && hipStreamGetPriority(s, &prio) == hipSuccess;       // (the NULL stream has the default priority)
+    (void)hipGetLastError();
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    c->prio_stream = s;
+    c->prio_seen = true;
+    c->prio_ok = !(known && prio == c->side_prio && least != greatest);
+    return c->prio_ok;
+}
+
 // the launch's side of the handshake: a new `started` number; wait_epoch is filled in by whoever knows which exchange the launch needs
 static GhHaloWait halo_flag_launch_args(Comm *c)
 {
-    // GH_HALO_MEMOPS (bit 1: the wait, bit 0: the flag write) hands the two side-stream operations to the command processor
-    // (hipStreamWaitValue32 on signal memory / hipStreamWriteValue32) instead of one-wave kernels.  Measured (tools/sweep.py shard_memops,
-    // 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- hence 2.
-    const bool sig_wait = (GH_TUNE_INT("GH_HALO_MEMOPS", 2) & 2) && c->started_sig;
+    // The two side-stream operations are one-wave kernels whose waits are BOUNDED (GH_HALO_WAIT_MS): whatever happens to the launch or the
+    // exchange, every wave on either stream reaches its exit.  GH_HALO_MEMOPS (probe builds; bit 1: the wait, bit 0: the flag write) hands them
+    // to the command processor instead (hipStreamWaitValue32 on signal memory / hipStreamWriteValue32).  Measured (tools/sweep.py
+    // shard_memops, 2048-row shard): kernels 38.4 us per step, the wait as a memory operation 37.6, the write as one 42.0 -- but a
+    // command-processor wait has no time-out: if the launch it waits for never starts, the side stream is stuck for good.  0.8 us per step
+    // does not pay for that, so the kernels are what ships.
+    const bool sig_wait = (GH_LAB_INT("GH_HALO_MEMOPS", 0) & 2) && c->started_sig;
     GhHaloWait hw{};
     hw.flag = c->flag_dev;
     hw.started = sig_wait ? c->started_sig : c->flag_dev + 32;
     hw.timeouts = c->timeouts_dev;
     hw.epoch = ++c->epoch;
-    hw.ticks = (unsigned long long)GH_TUNE_INT("GH_HALO_WAIT_MS", 10000) * 100000ull;       // 100 MHz constant clock
+    hw.ticks = (unsigned long long)(c->halo_wait_ms >= 0 ? c->halo_wait_ms : GH_KNOB_INT("GH_HALO_WAIT_MS", 10000)) * 100000ull;       // 100 MHz constant clock
     return hw;
 }
 
@@ -371,7 +452,7 @@ static int halo_flag_exchange(Comm *c, const GhHaloWait &hw, uint8_t *buf, size_
     if (int rc = gh_halo_exchange_dev(c, up, buf + row_bytes, buf, down, buf + (size_t)rows * row_bytes, buf + (size_t)(rows + 1) * row_bytes, row_bytes, c->side))
         return rc;
     const uint32_t f = ++c->xepoch;
-    if (GH_TUNE_INT("GH_HALO_MEMOPS", 2) & 1) {
+    if (GH_LAB_INT("GH_HALO_MEMOPS", 0) & 1) {
         GH_HIP_TRY(hipStreamWriteValue32(c->side, c->flag_dev, f, 0));
     } else {
         k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, f);
@@ -393,8 +474,9 @@ template <typename Launch, typename LaunchWait>
 static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipStream_t s, Launch launch /* (first_row, nrows, top_border, bot_border) */,
                         LaunchWait launch_wait /* (top_border, bot_border, const GhHaloWait &): the whole shard, edge bands wait for the flag */)
 {
-    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
-    if (c->loopback) up = down = c->rank;      // a middle shard whose neighbours are itself: halo = its own edge rows
+    int up, down;
+    neighbours(c, up, down);
+    forget_announced(c);
     if (up < 0 && down < 0) return launch(0, rows, 1, 1);
     uint8_t *send_up = buf + row_bytes, *recv_up = buf, *send_down = buf + (size_t)rows * row_bytes, *recv_down = buf + (size_t)(rows + 1) * row_bytes;
     // Three forms (GH_SHARD_STEP_FORM / gh_comm_set_step_form; loopback rehearsal, 16384-wide shards of 2048 / 4096 / 8192 rows, us per step;
@@ -407,11 +489,11 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     //    is not hidden: 40.0 / 62.7 / 110.7 (round 2's default).
     //  0 overlapped with events: exchange on the side stream || interior rows, then two one-row launches behind an event -- pays two
     //    cross-queue event hand-overs (~20 us each on this runtime) and two extra launches: 58.2 / 66.9 / 116.7.
-    int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
+    int form = c->step_form >= 0 ? c->step_form : GH_KNOB_INT("GH_SHARD_STEP_FORM", 2);
     if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
         GhHaloWait probe{};
         probe.pad = 1;
-        if (launch_wait(up < 0, down < 0, probe) != GH_OK) form = 1;
+        if (launch_wait(up < 0, down < 0, probe) != GH_OK || !caller_stream_ok(c, s)) form = 1;
     }
     if (form == 1) {
         if (int rc = gh_halo_exchange_dev(c, up, send_up, recv_up, down, send_down, recv_down, row_bytes, s)) return rc;
@@ -521,8 +603,8 @@ static int prefetch_halos(Comm *c, uint8_t *const *bufs, int n, size_t row_bytes
 template <typename Launch>
 static int sharded_step_pipelined(Comm *c, uint8_t *cur, uint8_t *prefetch, size_t row_bytes, int rows, hipStream_t s, Launch launch)
 {
-    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
-    if (c->loopback) up = down = c->rank;
+    int up, down;
+    neighbours(c, up, down);
     if (up < 0 && down < 0) return launch(cur, 1, 1);
     int entry = pf_find(c, cur);
     if (entry < 0) {
@@ -577,8 +659,8 @@ int gh_sharded_prefetch_halos_dev(gh_comm_t comm, uint8_t *const *bufs, int n, s
     GH_REQUIRE(rows >= 1 && row_bytes >= 1, "empty shard");
     for (int k = 0; k < n; ++k) GH_REQUIRE(bufs[k], "null buffer");
     Comm *c = static_cast<Comm *>(comm);
-    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
-    if (c->loopback) up = down = c->rank;
+    int up, down;
+    neighbours(c, up, down);
     if (up < 0 && down < 0) return GH_OK;             // a single rank: nothing to exchange
     for (int k = 0; k < n; ++k) {                      // a buffer asked for again: its old request is forgotten
         const int i = pf_find(c, bufs[k]);
@@ -613,13 +695,13 @@ template <typename LaunchWait, typename Plain, typename Fallback>
 static int sharded_stream_step(Comm *c, uint8_t *cur, uint8_t *next, size_t rb, int rows, hipStream_t s, LaunchWait launch_wait /* (tb, bb, hw) */,
                                Plain plain /* () : no neighbours */, Fallback fallback /* () */)
 {
-    int up = c->rank > 0 ? c->rank - 1 : -1, down = c->rank + 1 < c->world ? c->rank + 1 : -1;
-    if (c->loopback) up = down = c->rank;
+    int up, down;
+    neighbours(c, up, down);
     if (up < 0 && down < 0) return plain();
     GhHaloWait probe{};
     probe.pad = 1;
-    const int form = c->step_form >= 0 ? c->step_form : GH_TUNE_INT("GH_SHARD_STEP_FORM", 2);
-    if (form != 2 || launch_wait(up < 0, down < 0, probe) != GH_OK) return fallback();
+    const int form = c->step_form >= 0 ? c->step_form : GH_KNOB_INT("GH_SHARD_STEP_FORM", 2);
+    if (form != 2 || launch_wait(up < 0, down < 0, probe) != GH_OK || !caller_stream_ok(c, s)) return fallback();
     if (gh_comm_halo_timeouts(c))
         return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",
                             gh_comm_halo_timeouts(c));

@@ -384,7 +384,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         if (R <= 0) R = (height >= 22 && !(GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(wb, 22, 16))) ? 22 : 16;
         stream_core::BandPlan plan = stream_core::make_band_plan(height, R, -1, 0, -1, 0);
         // pairs-per-XCD dispatch order (8): 0.290 ms against 0.293 (band-per-XCD) / 0.294 (plain) on 16384^2, ahead on 16368 / 16370 too
-        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x);
+        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x, gh_num_xcd());
         const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const int unal = aligned ? 0 : ((wb % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
@@ -416,7 +416,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         }
         stream_core::BandPlan plan{};
         plan.bands = (height + R - 1) / R;
-        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x);   // band-per-XCD, as the fused kernel
+        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x, gh_num_xcd());   // band-per-XCD, as the fused kernel
         const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan.order, t);

@@ -597,7 +597,7 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
             // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
             BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
                                                  GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 6), plan.bands, groups_x);
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 6), plan.bands, groups_x, gh_num_xcd());
             
             GH_REQUIRE(stream_core::plan_grid(plan, groups_x) < (1ll << 31), "frame too large for one launch");
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);

@@ -155,19 +155,34 @@ __device__ __forceinline__ uint32_t gh_sobel_mag(int m)
 }
 
 
-// Tuning knobs (environment variables): read once per process; with GH_TUNE_DYNAMIC set they are re-read on every
-// launch so that an A/B tool (tools/ab_fused.py) can interleave variants inside one process.
+// Environment knobs, two kinds.
+//   GH_KNOB_INT  the few run-time settings of the RELEASE library (INTEGRATION.md lists them): read once per process.
+//   GH_LAB_INT   tuning and probe knobs of the measurement lab: they exist only in builds with -DGH_ENABLE_PROBES (`make probes` ->
+//                build_probes/libgrayhip_probes.so, what tools/ and the variant-sweeping tests load); in the release library the macro IS its
+//                default, a compile-time constant, and the kernel variants those knobs select are not compiled in.  With GH_TUNE_DYNAMIC
+//                set a probe build re-reads every knob on each launch, so that an A/B tool can interleave variants inside one process.
 #include <cstdlib>
 inline int gh_env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
+#ifdef GH_ENABLE_PROBES
+#define GH_LAB 1
 inline bool gh_tune_dynamic()
 {
     static const bool d = getenv("GH_TUNE_DYNAMIC") != nullptr;
     return d;
 }
-#define GH_TUNE_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return gh_tune_dynamic() ? gh_env_int(name, dflt) : v_; }())
+#define GH_LAB_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return gh_tune_dynamic() ? gh_env_int(name, dflt) : v_; }())
+#define GH_KNOB_INT(name, dflt) GH_LAB_INT(name, dflt)
+#else
+#define GH_LAB 0
+#define GH_LAB_INT(name, dflt) (dflt)
+#define GH_KNOB_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return v_; }())
+#endif
+// (interim, files not yet split into release / lab dispatch: the old always-on knob)
+inline bool gh_tune_dynamic_old() { static const bool d = getenv("GH_TUNE_DYNAMIC") != nullptr; return d; }
+#define GH_TUNE_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return gh_tune_dynamic_old() ? gh_env_int(name, dflt) : v_; }())
 
 #endif  // __HIPCC__

@@ -965,7 +965,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
             // dispatch order 8 (pairs-per-XCD: XCD x owns the band pairs p = x mod 8): +1-2 % on 16384^2 in four interleaved
             // A/B runs, +14 % on 32768 x 8192, neutral on shards (tools/ab_fused.py --op sobel)
             stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), plan.bands, groups_x);
+            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), plan.bands, groups_x, gh_num_xcd());
             const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
             
             const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
@@ -993,7 +993,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 if ((d4 == 2 || d4 == 3 || d4 == 6) && (R4 + 2) % chk4 == 0 && (R4 + 2) / chk4 >= 3 && rows >= R4) {
                     if (hw && hw->pad) return GH_OK;
                     stream_core::BandPlan p4 = stream_core::make_band_plan(rows, R4, -1, 0, -1, 0);
-                    p4.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p4.bands, gx4);
+                    p4.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p4.bands, gx4, gh_num_xcd());
                     const unsigned g4 = (unsigned)stream_core::plan_grid(p4, gx4);
                     gh_note_kernel(core4 ? "k_sobel_dma4 packed-f32 magnitude" : "k_sobel_dma4");
                     if (d4 == 2) { if (core4) k_sobel_dma4<2, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<2, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
@@ -1033,7 +1033,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 if (regular && wanted) {
                     if (hw && hw->pad) return GH_OK;      // probe: k_sobel_dma2 will run
                     stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
-                    p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2);
+                    p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2, gh_num_xcd());
                     const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
 #ifdef GH_ENABLE_PROBES
                     const int nsd = GH_TUNE_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: DESIGN.md)
@@ -1092,7 +1092,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 // wide-strip probe: dma = 100 * KiB per wave and row + ring depth (8 and 16 KiB: two / one wave per workgroup)
                 const int pieces = dma >= 1700 ? 1 : dma / 100, wpb = pieces >= 16 ? 1 : (pieces >= 8 ? 2 : 4), gxw = width / (1024 * pieces * wpb);
                 stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), pw.bands, gxw);
+                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), pw.bands, gxw, gh_num_xcd());
                 const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
                 if (dma == 203) k_wide_strip_probe<2, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
                 else if (dma == 202) k_wide_strip_probe<2, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
@@ -1111,7 +1111,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                 const int pieces = (dma - 30000) / 100, depth = dma % 100, wpb = pieces >= 12 ? (depth == 3 ? 1 : 2) : (pieces >= 6 ? (depth == 3 ? 2 : 4) : 4);
                 const int gxw = width / (1024 * pieces * wpb);
                 stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 6), pw.bands, gxw);
+                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 6), pw.bands, gxw, gh_num_xcd());
                 const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
                 if (dma == 30302) k_wide_strip_probe<3, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
                 else if (dma == 30303) k_wide_strip_probe<3, 3, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);

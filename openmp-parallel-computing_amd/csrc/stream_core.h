@@ -616,13 +616,16 @@ inline long long plan_grid(const BandPlan &plan, int groups_x)
     return bands * groups_x;
 }
 
-// host side: drop the parts of a mapping request that would not be a permutation of the (band, column) pairs
-inline int sanitize_order(int order, int bands, int groups_x)
+// host side: drop the parts of a mapping request that would not be a permutation of the (band, column) pairs -- and the XCD-interleaved
+// mappings (M = 4, 6, 8: "workgroup b runs on XCD b % 8") on a device that does not have the eight XCDs they are written for (a CPX
+// partition has one: the interleave would only scatter its bands and pad its grids to multiples of 8 / 16)
+inline int sanitize_order(int order, int bands, int groups_x, int num_xcd = GH_REF_NUM_XCD)
 {
     if (order <= 0) return 0;
     int M = order % 10, C = (order / 10) % 10, S = (order / 100) % 10, A = (order / 1000) % 10;
     const unsigned strides[10] = {1, 37, 3, 5, 7, 11, 13, 17, 19, 23};
     if (M != 0 && M != 2 && M != 4 && M != 6 && M != 8) M = 0;
+    if (num_xcd != GH_REF_NUM_XCD && (M == 4 || M == 6 || M == 8)) M = 0;
     if (M == 4 && ((long long)bands * groups_x) % 8 != 0) M = 0;
     if (S && (unsigned)bands % strides[S] == 0) S = 0;
     if (bands < 2 || A > 2) A = 0;          // A = 1: alternating heights; A = 2: odd bands walk upward

@@ -129,9 +129,24 @@ class NativeHaloComm:
         abi.check(self.lib.gh_comm_init(ident, rank, world, C.byref(handle)), "gh_comm_init")
         self.handle = handle
 
-    def set_loopback(self, on: bool = True):
-        """One-GPU rehearsal: both neighbours of the sharded steps are this rank (see gh_comm_set_loopback)."""
-        self.abi.check(self.lib.gh_comm_set_loopback(self.handle, int(on)), "gh_comm_set_loopback")
+    LOOPBACK_OFF, LOOPBACK_MIDDLE, LOOPBACK_TOP, LOOPBACK_BOTTOM = 0, 1, 2, 3
+
+    def set_loopback(self, mode=1):
+        """One-GPU rehearsal (gh_comm_set_loopback): the sharded steps treat this rank as a MIDDLE shard whose neighbours are itself
+        (1 / True), as the TOP shard -- frame border above, itself below -- (2) or as the BOTTOM shard (3); 0 / False: off."""
+        self.abi.check(self.lib.gh_comm_set_loopback(self.handle, int(mode)), "gh_comm_set_loopback")
+
+    def set_halo_wait_ms(self, ms: int):
+        """Bound of the halo-flag form's device-side waits on this communicator (-1: GH_HALO_WAIT_MS / 10 s)."""
+        self.abi.check(self.lib.gh_comm_set_halo_wait_ms(self.handle, int(ms)), "gh_comm_set_halo_wait_ms")
+
+    def halo_timeouts(self) -> int:
+        return int(self.lib.gh_comm_halo_timeouts(self.handle))
+
+    def check(self):
+        """Call after the synchronisation that hands a sharded step's output to the host: raises GrayHipError when a halo-flag wait of
+        the steps so far gave up (a neighbour's rows did not arrive within the bound) -- that output must not be used."""
+        self.abi.check(self.lib.gh_comm_check(self.handle), "gh_comm_check")
 
     def set_step_form(self, form: int):
         """Form of the single-frame sharded steps: 2 halo flag (default), 1 serial, 0 events, -1 = environment / default."""
@@ -345,12 +360,14 @@ class ShardedGraySobel:
         self._ops = None
         self._gray_for = None          # (data_ptr of the last rgb shard, bound launcher)
         self._native = None            # exchange + Sobel launches issued by libgrayhip itself (NativeHaloComm)
+        self._native_comm = None
         b, g = backend, geom
         if rows == 0:
             return
         if native_comm is not None and g.world > 1 and not g.has_empty_shards:
             assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
             self._native = native_comm.bind_sobel_step(self.luma, self.edge, rows)
+            self._native_comm = native_comm
             return
         if g.world == 1:
             self._whole = _bind(b, "sobel_rows", b.sobel_rows, self.luma, self.edge, rows, True, True)
@@ -377,6 +394,15 @@ class ShardedGraySobel:
                 ops.append(dist.P2POp(dist.irecv, buf[g.rows + 1], g.rank + 1, self.group))
             self._ops = ops
         return self._ops
+
+    def result(self):
+        """The edge plane of the last step() for the HOST: synchronises the current stream and -- native exchange -- checks that no
+        halo-flag wait gave up (step() itself is asynchronous and cannot know)."""
+        import torch
+        torch.cuda.current_stream().synchronize()
+        if self._native_comm is not None:
+            self._native_comm.check()
+        return self.edge
 
     def step(self, rgb_shard):
         import torch.distributed as dist
@@ -429,12 +455,14 @@ class ShardedFusedGraySobel:
         self.edge = torch.empty((rows, geom.width), dtype=torch.uint8, device=device)
         self._ops = None
         self._native = None            # exchange + fused launches issued by libgrayhip itself (NativeHaloComm)
+        self._native_comm = None
         b, g = backend, geom
         if rows == 0:
             return
         if native_comm is not None and g.world > 1 and not g.has_empty_shards:
             assert (native_comm.rank, native_comm.world) == (g.rank, g.world)
             self._native = native_comm.bind_fused_step(self.rgb, self.edge, rows, getattr(backend, "mode", 0))
+            self._native_comm = native_comm
             return
         if g.world == 1:
             self._whole = _bind(b, "fused_rows", b.fused_rows, self.rgb, self.edge, rows, True, True)
@@ -449,6 +477,15 @@ class ShardedFusedGraySobel:
     @property
     def shard(self):
         return self.rgb[1:self.g.rows + 1]
+
+    def result(self):
+        """The edge plane of the last step() for the HOST: synchronises the current stream and -- native exchange -- checks that no
+        halo-flag wait gave up (step() itself is asynchronous and cannot know)."""
+        import torch
+        torch.cuda.current_stream().synchronize()
+        if self._native_comm is not None:
+            self._native_comm.check()
+        return self.edge
 
     def _exchange_ops(self):
         import torch.distributed as dist
@@ -599,6 +636,14 @@ class ShardedPipelineGraySobel:
     @property
     def shard(self):
         return self.img[1:self.g.rows + 1]
+
+    def result(self):
+        """The last run()'s edge plane for the HOST: synchronises, then checks the communicator (see ShardedFusedGraySobel.result)."""
+        import torch
+        torch.cuda.current_stream().synchronize()
+        if self._native_comm is not None:
+            self._native_comm.check()
+        return self.edge
 
     def run(self, passes: int = 1):
         g, b, rows = self.g, self.backend, self.g.rows

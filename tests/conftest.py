@@ -70,6 +70,29 @@ def cli_crop():
     return dict(np.load(os.path.join(GOLDEN, "cli_crop.npz"), allow_pickle=False))
 
 
+LOOPBACK_MODES = [1, 2, 3]          # gh_comm_set_loopback: this rank as a middle shard, as the top shard, as the bottom shard
+
+
+def loopback_pad(a: np.ndarray, lb: int):
+    """What a shard in loopback mode `lb` sees beyond its edges: a copy of its own first row above (modes 1 and 3: the "neighbour" is
+    the shard itself) and of its own last row below (modes 1 and 2); on the other side the frame border.  Returns (padded rows, number of
+    rows added above, below)."""
+    top = [a[:1]] if lb in (1, 3) else []
+    bot = [a[-1:]] if lb in (1, 2) else []
+    return np.concatenate(top + [a] + bot, axis=0), len(top), len(bot)
+
+
+def loopback_sobel(oracle, plane: np.ndarray, lb: int) -> np.ndarray:
+    """Edge plane of a shard holding `plane` in loopback mode lb: the oracle on the padded plane, the added rows cropped; the frame-border
+    side keeps the zero row the reference's untouched border stands for (monolithic/src/sobel.c:11-12), columns 0 and w-1 are border."""
+    padded, nt, nb = loopback_pad(plane, lb)
+    e = oracle.sobel(padded)
+    e = e[nt:e.shape[0] - nb].copy()
+    e[:, 0] = 0
+    e[:, -1] = 0
+    return e
+
+
 def make_frame(oracle, name: str, spec: dict) -> np.ndarray:
     gen, w, h = spec["gen"], spec["w"], spec["h"]
     if gen == "cube":

@@ -1,6 +1,7 @@
 // Prints the host-side launch-rule helpers of stream_core.h for a list of cases (tests/test_launch_rules.py compares them with
 // a Python restatement and with the figures DESIGN.md quotes).  Host code only: built with hipcc, runs without a GPU.
 #include <cstdio>
+#include <utility>
 #include "stream_core.h"
 int main()
 {
@@ -28,5 +29,13 @@ int main()
             printf("rows_sobel %d %d %d %d\n", cus, f[0], f[1], stream_core::sobel_band_rows(gx, f[1], f[0], cus, true, true, true));
             printf("rows_fused_shard %d %d %d %d\n", cus, f[0], f[1], stream_core::fused_band_rows(gx, f[1], 3ll * f[0], cus, true, true));
         }
+    // workgroup -> band mapping requests as sanitised for a device with `xcds` XCDs: "order xcds bands groups_x requested granted grid"
+    for (int xcds : {8, 1, 4})
+        for (int req : {0, 6, 8, 4, 2, 2006, 108, 16})
+            for (const auto &bg : {std::pair<int, int>{256, 4}, {32, 4}, {33, 2}, {1, 4}}) {
+                stream_core::BandPlan p = stream_core::make_band_plan(bg.first * 64, 64, -1, 0, -1, 0);
+                p.order = stream_core::sanitize_order(req, p.bands, bg.second, xcds);
+                printf("order %d %d %d %d %d %lld\n", xcds, bg.first, bg.second, req, p.order, stream_core::plan_grid(p, bg.second));
+            }
     return 0;
 }

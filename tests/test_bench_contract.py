@@ -118,6 +118,61 @@ def test_committed_pmc_summary_is_consistent():
     assert t is not None and cross["ratio"] == pytest.approx(1.0, abs=1e-3)
 
 
+def test_watchdog_writes_the_line_it_has_and_ends_the_process():
+    """N > 1: a phase that outlives its wall-clock budget (a peer that never answers) must not cost the run its line.  The watchdog
+    thread of rank 0 writes what has been measured -- here a `value` whose checks were good: exit code 0 -- and ends the process;
+    before `value` exists the line says so (value null + error) and the exit code is 5; other ranks write nothing."""
+    code = (
+        "import importlib.util, json, os, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "rank, have_value = int(sys.argv[1]), sys.argv[2] == '1'\n"
+        "wd = b.Watchdog(1, rank, {'metric': 'm', 'value': None, 'n_gpus': 2})\n"
+        "wd.arm('setup', 30); wd.disarm()\n"
+        "if have_value:\n"
+        "    wd.partial.update({'value': 123.0, 'step_forms': {'single_frame': {'ms_per_step': 1.0}}}); wd.good = True\n"
+        "wd.arm('stream_of_frames', 0.6)\n"
+        "time.sleep(30)\n"
+        "print('not reached')\n")
+    for rank, have_value, want_rc in ((0, True, 0), (0, False, 5), (1, True, 0)):
+        p = subprocess.run([sys.executable, "-c", code, str(rank), "1" if have_value else "0"], capture_output=True, text=True, timeout=60)
+        assert p.returncode == want_rc, (p.returncode, p.stderr[-500:])
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        if rank != 0:
+            assert lines == []
+            continue
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert "stream_of_frames exceeded its wall-clock budget" in out["watchdog"] and "setup" in out["wall_clock_s"]
+        if have_value:
+            assert out["value"] == 123.0 and "error" not in out and out["step_forms"]["single_frame"]["ms_per_step"] == 1.0
+        else:
+            assert out["value"] is None and "exceeded" in out["error"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inject,budget_scale", [("fail:pipelined", "1"), ("fail:end_to_end_h2d", "1"), ("hang:stream_of_frames", "0.1")])
+def test_a_failing_optional_form_does_not_cost_the_line(inject, budget_scale):
+    """bench.py --gpus N: once `value` (the single-frame form) is measured and its checks are good, an optional form that throws lands
+    in the line as step_forms.<name>.error, one that never returns is cut off by the watchdog -- rc 0 and ONE line with `value` both times."""
+    env = dict(os.environ, GH_BENCH_REHEARSAL="loopback", GH_BENCH_INJECT=inject, GH_BENCH_BUDGET_SCALE=budget_scale)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--width", "4096", "--height", "4096", "--steps", "4",
+                        "--warmup", "1", "--settle-ms", "20"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    name = inject.split(":")[1]
+    assert out["value"] > 0 and out["step_forms"]["single_frame"]["ms_per_step"] > 0
+    if inject.startswith("fail"):
+        assert "injected" in out["step_forms"][name]["error"] and out["step_forms"][name]["wall_s"] >= 0
+        others = [k for k in ("end_to_end_h2d", "stream_of_frames", "pipelined") if k != name]
+        assert all(out["step_forms"][k]["ms_per_step"] > 0 for k in others)
+        assert out["wall_clock_s"]["single_frame (value)"] > 0
+    else:
+        assert name in out["watchdog"] and out["incomplete"]
+
+
 @pytest.mark.gpu
 def test_plain_command_runs_two_ranks_in_rehearsal():
     """The driver's plain form: `python3 bench.py --gpus 2` (no torchrun).  On a one-GPU box the two ranks share the GPU
@@ -159,6 +214,7 @@ def test_loopback_rehearsal_drives_the_native_step_forms():
     assert out["exchange_fallback"] is False and out["exchange_issuer"].startswith("libgrayhip")
     assert out["shard_step_form"].startswith("halo flag")
     assert out["step_forms"]["single_frame"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.01)
+    assert out["wall_clock_s"]["single_frame (value)"] > 0 and out["step_forms"]["pipelined"]["wall_s"] > 0      # the run's own clock per form
     assert out["step_forms"]["pipelined"]["exchanges_per_step"] == pytest.approx(1.0, abs=0.02)       # one per frame, beside the previous frame's launch
     assert out["step_forms"]["pipelined_batched"]["exchanges_per_step"] <= 0.35    # four frames per exchange (+ the cold start)
     assert out["step_forms"]["stream_of_frames"]["exchanges_per_step"] if "exchanges_per_step" in out["step_forms"]["stream_of_frames"] else True

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import LOOPBACK_MODES, loopback_pad, loopback_sobel
+
 from conftest import make_frame
 
 pytestmark = pytest.mark.gpu
@@ -530,24 +532,24 @@ def test_native_comm_self_exchange(pkg, native_comm, torch_mod):
     assert sums.cpu().tolist() == [1, 2, 3]
 
 
-@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130), (16384, 2048), (1031, 70), (8192, 128), (512, 20)])
-@pytest.mark.parametrize("form", ["2", "1", "0"])
-def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, monkeypatch):
+@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130), (16384, 2048), (1031, 70), (8192, 128), (512, 20), (16384, 64), (4096, 1)])
+@pytest.mark.parametrize("form", [2, 1, 0])
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, lb):
     """The C++ sharded step in its three forms -- 2 halo flag (default: exchange on the side stream beside ONE launch whose first /
     last band wait for a flag inside the kernel), 1 serial (exchange on the caller's stream, then one launch), 0 overlapped with
-    events (exchange || interior rows, then first / last row) -- as a middle shard whose neighbours are itself: the halo rows must
-    become copies of the shard's own edge rows, i.e. the result equals the oracle on the frame padded by replicating its first and
-    last row.  The halo rows start out poisoned and the steps are repeated, so a band that did not wait for its halo shows."""
-    monkeypatch.setenv("GH_SHARD_STEP_FORM", form)
+    events (exchange || interior rows, then first / last row) -- as each of the three kinds of shard a multi-GPU job has: a middle
+    shard (lb 1), the top shard (lb 2: frame border above -- monolithic/src/sobel.c:11-12 -- and ONE halo row, below), the bottom shard
+    (lb 3), the neighbours being this rank itself: a halo row becomes a copy of the shard's own edge row, so the result equals the
+    oracle on the frame padded by replicating that row on the neighbour side only.  The halo rows start out poisoned and the steps
+    are repeated, so a band that did not wait for its halo row shows -- and so does a border band that READ the row beyond the frame."""
     t = torch_mod
     img = oracle.frame_rand(w, h, 3, seed=w * 7 + h)
-    padded = np.concatenate([img[:1], img, img[-1:]], axis=0)
-    want = oracle.sobel(oracle.gray_to_plane(padded, 0))[1:-1]
-    want[:, 0] = 0
-    want[:, -1] = 0
-    native_comm.set_loopback(True)
+    want = loopback_sobel(oracle, oracle.gray_to_plane(img, 0), lb)
+    up, down = lb in (1, 3), lb in (1, 2)
+    native_comm.set_loopback(lb)
+    native_comm.set_step_form(form)
     try:
-        geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
         backend = pkg.sharding.HipBackend(0)
         # fused: RGB halo rows
         buf = t.full((h + 2, w, 3), 0xA5, dtype=t.uint8, device="cuda")
@@ -556,15 +558,17 @@ def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h
         step = native_comm.bind_fused_step(buf, edge, h, 0)
         step()                          # the very first step: halo rows still poisoned when the launch is enqueued
         t.cuda.synchronize()
+        native_comm.check()
         assert np.array_equal(edge.cpu().numpy(), want)
         for _ in range(3):              # repeated steps: the exchange of step k+1 must wait for step k's edge rows
             buf[0] = 0x5A               # (enqueued on the same stream, in front of the step)
             buf[h + 1] = 0x5A
             step()
         t.cuda.synchronize()
-        assert np.array_equal(buf[0].cpu().numpy(), img[0]) and np.array_equal(buf[h + 1].cpu().numpy(), img[-1])
+        native_comm.check()
+        assert np.array_equal(buf[0].cpu().numpy(), img[0] if up else np.full_like(img[0], 0x5A))       # border side: never written
+        assert np.array_equal(buf[h + 1].cpu().numpy(), img[-1] if down else np.full_like(img[0], 0x5A))
         assert np.array_equal(edge.cpu().numpy(), want)
-        assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
         # split: luma halo rows
         luma = t.full((h + 2, w), 0xA5, dtype=t.uint8, device="cuda")
         backend.gray_to_plane(dev(t, img), luma[1:h + 1])
@@ -577,11 +581,11 @@ def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h
         luma[h + 1] = 0x5A
         step2(); step2()
         t.cuda.synchronize()
+        native_comm.check()
         assert np.array_equal(edge2.cpu().numpy(), want)
-        assert pkg.abi.load().gh_comm_halo_timeouts(native_comm.handle) == 0
-        del geom
     finally:
-        native_comm.set_loopback(False)
+        native_comm.set_step_form(-1)
+        native_comm.set_loopback(0)
 
 
 def test_native_pipelined_steps_loopback(pkg, oracle, native_comm, torch_mod):

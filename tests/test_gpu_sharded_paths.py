@@ -6,6 +6,8 @@ shard's own first / last row).  The exchange protocol across ranks is covered wi
 import numpy as np
 import pytest
 
+from conftest import LOOPBACK_MODES, loopback_pad, loopback_sobel
+
 pytestmark = pytest.mark.gpu
 
 GAUSS, BOX, SIGNED, SHARPEN = [1, 2, 1, 2, 4, 2, 1, 2, 1], [1] * 9, [-1, -2, -1, 0, 0, 0, 1, 2, 1], [0, -1, 0, -1, 5, -1, 0, -1, 0]
@@ -68,15 +70,20 @@ def _replicate_padded(img):
 
 
 @pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (342, 17), (5464, 2), (4099, 35), (64, 1)])
-def test_native_sharded_conv_step_loopback(pkg, oracle, native_comm, torch_mod, w, h):
-    """gh_sharded_conv3x3_step_dev as a middle shard whose neighbours are itself: the halo rows become copies of the shard's own
-    first and last RGB row, so the result equals the oracle on the frame padded by replicating those rows (left / right: zero border)."""
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_native_sharded_conv_step_loopback(pkg, oracle, native_comm, torch_mod, w, h, lb):
+    """gh_sharded_conv3x3_step_dev as a middle / top / bottom shard whose neighbours are itself: a halo row becomes a copy of the shard's
+    own first / last RGB row, so the result equals the oracle on the frame padded by replicating that row on the neighbour side
+    (frame-border side and left / right: the zero border)."""
     t = torch_mod
     img = oracle.frame_rand(w, h, 3, seed=w * 11 + h)
-    native_comm.set_loopback(True)
+    up, down = lb in (1, 3), lb in (1, 2)
+    native_comm.set_loopback(lb)
     try:
         for kern, norm in ((GAUSS, 16), (BOX, 9), (SHARPEN, 1)):
-            want = oracle.conv3x3(_replicate_padded(img), kern, norm)[1:-1]
+            padded, nt, nb = loopback_pad(img, lb)
+            want = oracle.conv3x3(padded, kern, norm)
+            want = want[nt:want.shape[0] - nb]
             buf = t.full((h + 2, w, 3), 0x77, dtype=t.uint8, device="cuda")
             buf[1:h + 1] = dev(t, img)
             out = t.full((h, w, 3), 9, dtype=t.uint8, device="cuda")
@@ -86,7 +93,8 @@ def test_native_sharded_conv_step_loopback(pkg, oracle, native_comm, torch_mod, 
             step()                      # the second step's exchange must wait for the first step's reads of the halo rows
             t.cuda.synchronize()
             assert native_comm.exchange_count() - n0 == 2
-            assert np.array_equal(buf[0].cpu().numpy(), img[0]) and np.array_equal(buf[h + 1].cpu().numpy(), img[-1])
+            assert np.array_equal(buf[0].cpu().numpy(), img[0] if up else np.full_like(img[0], 0x77))
+            assert np.array_equal(buf[h + 1].cpu().numpy(), img[-1] if down else np.full_like(img[0], 0x77))
             assert np.array_equal(out.cpu().numpy(), want), (kern, norm)
         # through the runner class, as bench / applications use it (world 1 -> plain launch, no exchange: zero border all round)
         geom = pkg.sharding.ShardGeometry(0, 1, w, 0, h)
@@ -94,21 +102,18 @@ def test_native_sharded_conv_step_loopback(pkg, oracle, native_comm, torch_mod, 
         runner.shard.copy_(dev(t, img))
         assert np.array_equal(runner.step().cpu().numpy(), oracle.conv3x3(img, GAUSS, 16))
     finally:
-        native_comm.set_loopback(False)
+        native_comm.set_loopback(0)
 
 
 # ---- monolithic/src/main_with_sobel.c:49-76 on a shard: one halo exchange per pass ------------------------------------------
 
-def _loopback_multipass(oracle, img, passes, mode):
-    """What a middle shard whose neighbours are itself must produce: before every pass the rows above / below the shard are copies
-    of the shard's own first / last row of that pass's input plane."""
+def _loopback_multipass(oracle, img, passes, mode, lb=1):
+    """What a shard whose neighbours are itself must produce (lb: middle / top / bottom shard): before every pass the row beyond a
+    neighbour-side edge is a copy of the shard's own first / last row of that pass's input plane."""
     h, w, c = img.shape
 
     def sobel_padded(plane):
-        e = oracle.sobel(_replicate_padded(plane))[1:-1].copy()
-        e[:, 0] = 0
-        e[:, -1] = 0
-        return e
+        return loopback_sobel(oracle, plane, lb)
 
     edge = None
     for p in range(passes):
@@ -126,13 +131,14 @@ def _loopback_multipass(oracle, img, passes, mode):
 
 @pytest.mark.parametrize("w,h,c", [(1024, 40, 3), (2064, 5, 3), (333, 77, 4), (4096, 3, 3), (1031, 33, 3), (64, 9, 1), (16384, 66, 3)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_native_sharded_multipass_pipeline_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, mode):
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_native_sharded_multipass_pipeline_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, mode, lb):
     t = torch_mod
     img = oracle.frame_rand(w, h, c, seed=w + 13 * h + c)
-    native_comm.set_loopback(True)
+    native_comm.set_loopback(lb)
     try:
-        for passes in (1, 2, 3):
-            want_img, want_edge = _loopback_multipass(oracle, img, passes, mode)
+        for passes in (1, 2, 3, 4):
+            want_img, want_edge = _loopback_multipass(oracle, img, passes, mode, lb)
             buf = t.full((h + 2, w, c), 0x66, dtype=t.uint8, device="cuda")
             buf[1:h + 1] = dev(t, img)
             gray = t.full((h + 2, w), 0x55, dtype=t.uint8, device="cuda")
@@ -144,8 +150,9 @@ def test_native_sharded_multipass_pipeline_loopback(pkg, oracle, native_comm, to
             assert native_comm.exchange_count() - n0 == passes                      # ONE exchange per pass
             assert np.array_equal(edge.cpu().numpy(), want_edge), passes
             assert np.array_equal(buf[1:h + 1].cpu().numpy(), want_img), passes     # in place, alpha untouched
+            native_comm.check()
     finally:
-        native_comm.set_loopback(False)
+        native_comm.set_loopback(0)
 
 
 @pytest.mark.parametrize("w,h,c,passes", [(1040, 40, 3, 3), (64, 48, 4, 2), (333, 20, 3, 1)])
@@ -200,7 +207,8 @@ def test_shard_kernel_beside_an_exchange_takes_fat_bands(pkg, oracle, native_com
 
 
 @pytest.mark.parametrize("w,h,c,nbuf", [(2064, 37, 3, 3), (16384, 70, 3, 2), (1031, 33, 4, 4), (4096, 2048 // 8, 3, 8), (512, 20, 3, 3), (2048, 40, 3, 1)])
-def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, nbuf):
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, h, c, nbuf, lb):
     """gh_sharded_fused_stream_step_dev: frame k is filtered by one launch while the halo rows of frame k + 1 travel beside it, the two
     sides meeting through the polled dwords only.  All frames differ and their halo rows start out poisoned, so a halo that reached
     the wrong buffer, arrived late or was never exchanged changes the result; then the frames are replaced between steps (the next
@@ -208,12 +216,9 @@ def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, 
     t = torch_mod
 
     def expected(img):
-        e = oracle.sobel(oracle.gray_to_plane(_replicate_padded(img), 0))[1:-1].copy()
-        e[:, 0] = 0
-        e[:, -1] = 0
-        return e
+        return loopback_sobel(oracle, oracle.gray_to_plane(img, 0), lb)
 
-    native_comm.set_loopback(True)
+    native_comm.set_loopback(lb)
     try:
         frames = [oracle.frame_rand(w, h, c, seed=300 + 7 * i + w) for i in range(nbuf)]
         bufs = []
@@ -261,9 +266,10 @@ def test_stream_step_halo_flag_loopback(pkg, oracle, native_comm, torch_mod, w, 
                     t.cuda.synchronize()
                     assert np.array_equal(edge.cpu().numpy(), expected(frames[k % nbuf])), ("sobel", k)
             t.cuda.synchronize()
+            native_comm.check()
             assert np.array_equal(edge.cpu().numpy(), expected(frames[(2 * nbuf + 1) % nbuf]))
     finally:
-        native_comm.set_loopback(False)
+        native_comm.set_loopback(0)
 
 
 def test_halo_flag_epochs_restart_before_they_could_wrap(pkg, oracle, torch_mod, monkeypatch):
@@ -301,10 +307,11 @@ def test_halo_flag_epochs_restart_before_they_could_wrap(pkg, oracle, torch_mod,
         comm.close()
 
 
-def test_a_halo_wait_that_gives_up_is_reported_not_hidden(pkg, oracle, torch_mod, monkeypatch):
-    """Every in-kernel wait is bounded (GH_HALO_WAIT_MS).  With the bound at zero the edge bands of a 2048-row shard ask for their halo
+def test_a_halo_wait_that_gives_up_is_reported_not_hidden(pkg, oracle, torch_mod):
+    """Every in-kernel wait is bounded (GH_HALO_WAIT_MS / gh_comm_set_halo_wait_ms).  With the bound at zero the edge bands of a 2048-row shard ask for their halo
     row before the exchange has landed and give up: the wave still finishes (the launch drains), the give-up is counted in host-mapped
-    memory, the NEXT halo-flag step fails loudly, the serial form keeps working, and choosing a form acknowledges the count."""
+    memory, gh_comm_check -- the call that belongs behind the synchronisation handing out the step's output -- refuses THAT step, the
+    next halo-flag step fails loudly too, the serial form keeps working, and choosing a form acknowledges the count."""
     t = torch_mod
     w, h = 16384, 2048
     comm = pkg.sharding.NativeHaloComm(0, 1)
@@ -321,15 +328,18 @@ def test_a_halo_wait_that_gives_up_is_reported_not_hidden(pkg, oracle, torch_mod
         step()
         t.cuda.synchronize()
         assert t.equal(edge, want) and pkg.abi.load().gh_comm_halo_timeouts(comm.handle) == 0
-        monkeypatch.setenv("GH_HALO_WAIT_MS", "0")
+        comm.set_halo_wait_ms(0)
         buf[0] = 0x11
         buf[h + 1] = 0x22
         step()
         t.cuda.synchronize()                                   # the launch drained although its waits gave up
-        monkeypatch.delenv("GH_HALO_WAIT_MS")
-        gave_up = pkg.abi.load().gh_comm_halo_timeouts(comm.handle)
+        comm.set_halo_wait_ms(-1)
+        gave_up = comm.halo_timeouts()
         if gave_up == 0:
             pytest.skip("the exchange landed before the edge bands asked for their halo row on this box")
+        with pytest.raises(pkg.GrayHipError) as ei:          # the check that belongs behind the synchronisation: THIS step's output is refused
+            comm.check()
+        assert "gave up" in str(ei.value)
         with pytest.raises(pkg.GrayHipError) as ei:
             step()
         assert "gave up" in str(ei.value)

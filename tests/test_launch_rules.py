@@ -127,3 +127,23 @@ def test_the_cases_design_md_quotes():
     assert balance(384) == 0.75 and round(balance(480), 2) == 0.94 and balance(256) == 1.0 and balance(512) == 1.0
     # a shifted last band must not add a layer of workgroups: 16384 x 8200 with two strips (258 on 256) does, 7680 x 4320 (2 x 270) does not
     assert overflows(2, 8200, 64) and overflows(1, 4100, 16) and not overflows(2, 4320, 16) and not overflows(1, 1080, 16)
+
+
+def test_xcd_interleaved_orders_only_on_eight_xcds(dump):
+    """band_of_block's orders 4 / 6 / 8 deal workgroups to "XCD b % 8"; on a device with another XCD count (a CPX partition has one)
+    the request falls back to the band-major order 0 and the grid is not padded to multiples of 8 / 16 bands."""
+    recs = [(int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(r[6])) for r in dump if r[0] == "order"]
+    assert len(recs) >= 90
+    for xcds, bands, gx, req, granted, grid in recs:
+        m_req, m = req % 10, granted % 10
+        if xcds != 8:
+            assert m in (0, 2), (xcds, req, granted)
+            assert grid == bands * gx, (xcds, bands, gx, req, grid)
+        elif m_req in (6, 8) and bands >= 1:
+            assert m == m_req
+            pad = 8 if m == 6 else 16
+            assert grid == -(-bands // pad) * pad * gx
+        if m_req == 2:
+            assert m == 2
+    # the headline plan on the whole chip and on one XCD of it
+    assert (8, 256, 4, 6, 6, 1024) in recs and (1, 32, 4, 6, 0, 128) in recs

@@ -21,7 +21,7 @@ KNOB_SETS = [{}, {"GH_FUSED_DMA": "2"}, {"GH_FUSED_DMA": "3"}, {"GH_FUSED_DMA": 
              {"GH_FUSED_DMA_UNALIGNED": "0", "GH_SOBEL_DMA_UNALIGNED": "0"}, {"GH_FUSED_DMA_UNALIGNED": "1", "GH_SOBEL_DMA_UNALIGNED": "1"},
              {"GH_SOBEL_NS": "1"}, {"GH_SOBEL_NS": "2"}, {"GH_CONV_R": "16"}, {"GH_CONV_ORDER": "0"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "64"}, {"GH_SOBEL_NS": "2", "GH_SOBEL_R": "16"},
              {"GH_SOBEL_NS": "4"}, {"GH_SOBEL_NS": "4", "GH_SOBEL_NS4_D": "2", "GH_SOBEL_R": "16"}, {"GH_SOBEL_NS": "4", "GH_SOBEL_NS4_CORE": "0", "GH_SOBEL_NS4_D": "6"},
-             {"GH_CONV_R": "22"}, {"GH_SHARD_STEP_FORM": "1"}, {"GH_SHARD_STEP_FORM": "0"}, {"GH_HALO_MEMOPS": "0"}, {"GH_HALO_MEMOPS": "3"}]
+             {"GH_CONV_R": "22"}, {"GH_HALO_MEMOPS": "2"}, {"GH_HALO_MEMOPS": "3"}]
 
 
 def run(secs: float, seed: int, verbose: bool = True):
@@ -43,7 +43,6 @@ def run(secs: float, seed: int, verbose: bool = True):
     comm = None
     try:
         comm = pkg.sharding.NativeHaloComm(0, 1)
-        comm.set_loopback(True)
     except Exception as exc:                                  # (no RCCL on this box: the kernels alone)
         if verbose:
             print("stress: no loopback communicator:", exc, flush=True)
@@ -81,8 +80,14 @@ def run(secs: float, seed: int, verbose: bool = True):
                 conv = (api.conv3x3(d, kern, norm), O.conv3x3(img, kern, norm))
             shard = None
             if comm is not None and h >= 3 and rnd.randint(3) == 0:
-                padded = np.concatenate([luma[:1], luma, luma[-1:]], axis=0)           # loopback: the halo rows are the shard's own edge rows
-                want_s = O.sobel(padded)[1:-1].copy()
+                # loopback: this rank as a middle (1), top (2) or bottom (3) shard -- a halo row is the shard's own edge row, the other side
+                # the frame border; the step in its halo-flag (mostly), serial or event form
+                lb = int(rnd.randint(1, 4))
+                comm.set_loopback(lb)
+                comm.set_step_form(int(rnd.choice([2, 2, 2, 1, 0])))
+                padded = np.concatenate(([luma[:1]] if lb in (1, 3) else []) + [luma] + ([luma[-1:]] if lb in (1, 2) else []), axis=0)
+                e_ = O.sobel(padded)
+                want_s = e_[(1 if lb in (1, 3) else 0):e_.shape[0] - (1 if lb in (1, 2) else 0)].copy()
                 want_s[:, 0] = 0
                 want_s[:, -1] = 0
                 buf = torch.full((h + 2, w, ch), 0xA5, dtype=torch.uint8, device="cuda")
@@ -113,9 +118,10 @@ def run(secs: float, seed: int, verbose: bool = True):
                     if not np.array_equal(e_.cpu().numpy(), shard[2]):
                         bad += 1
                         if verbose:
-                            print("MISMATCH sharded step", w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
-                if pkg.abi.load().gh_comm_halo_timeouts(comm.handle):
+                            print("MISMATCH sharded step (loopback mode %d)" % lb, w, h, ch, mode, {k: os.environ.get(k) for k in allk if k in os.environ}, flush=True)
+                if comm.halo_timeouts():
                     bad += 1
+                    comm.set_step_form(-1)                        # (acknowledges the count: the run goes on)
                     if verbose:
                         print("halo-flag wait timed out", flush=True)
             for o in outs:
