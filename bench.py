@@ -62,6 +62,7 @@ ALGO_BYTES_PER_PX = {          # each image byte counted
     "sobel3x3_u8": 2,            # 1 R + 1 W
     "sobel3x3_u8_after_gray": 2,  # the same kernel timed inside the gray -> Sobel pipeline (its input plane has just been written)
     "gray_inplace_rgb8": 6,      # 3 R + 3 W (the reference ABI's in-place form)
+    "pipeline_pass_k": 2,        # pass k >= 2 of main_with_sobel.c:51-74: the previous edge plane in (lum(e,e,e) applied on load), the next one out
 }
 M64 = (1 << 64) - 1
 
@@ -769,6 +770,7 @@ def main() -> int:
         # (a single 268 MB plane re-read launch after launch could be served by the 256 MB Infinity Cache).  Inside the split pipeline
         # above the same kernel is timed between two per-step event records, which cost it ~4 %: both figures are reported.
         sobel_alone = None
+        pass_k = None
         if not args.no_kernel_table:
             if not luma[1:rows + 1].any():                                   # (the split pipeline was the FIRST region or did not run)
                 chk(lib.gh_gray_rgb8_to_plane_dev(rgb_ptr, luma_ptr + W, rows * W, 3, mode, s_ptr), "gray")
@@ -793,7 +795,37 @@ def main() -> int:
                         print("bench.py: parity check FAILED in the third timed region", file=sys.stderr)
                         return 3
                 check += "; plane Sobel alone: all three edge planes == compiled reference"
-            del lumas, edges
+            del lumas
+            # fourth timed region: pass k >= 2 of the reference's multi-pass loop (main_with_sobel.c:51-74 on what the previous pass wrote) as
+            # ONE launch -- the plane Sobel with lum(e, e, e) applied on load, 1 R + 1 W byte per pixel; until round 4 a luma pass and a Sobel
+            # pass (4 B/px, two launches).  Inputs: the three pass-1 edge planes just checked; outputs rotate over three planes as well.
+            outs = [torch.empty_like(edge) for _ in range(3)]
+            ip, op = [t.data_ptr() for t in edges], [t.data_ptr() for t in outs]
+
+            def step_pass_k(k, ev):
+                chk(lib.gh_sobel_of_gray_u8_dev(ip[k % 3], op[k % 3], W, rows, mode, s_ptr), "sobel_of_gray")
+
+            rv4 = region_pair()
+            run_in(step_pass_k)
+            el4, _ = timed(step_pass_k, args.steps, None, rv4)
+            timed_kernels["pipeline_pass_k"] = rv4[0].elapsed_time(rv4[1]) / args.steps
+            kernel_forms["pipeline_pass_k"] = lib.gh_last_kernel().decode()
+            region_of["pipeline_pass_k"] = "fourth"
+            pass_k = {"pipeline": "pass k >= 2 of the gray+Sobel loop in one launch (gh_sobel_of_gray_u8_dev), inputs / outputs rotating over 3 planes",
+                      "ms_per_step": round(el4 / args.steps * 1e3, 4), "Mpixels/s": round(W * H_total * args.steps / el4 / 1e6, 1)}
+            if not args.no_check:
+                # the launch it replaces: gray_of_plane (lum(e,e,e) plane) then the plane Sobel -- both pinned above; bit for bit
+                tmp = torch.empty_like(edge)
+                chk(lib.gh_gray_of_plane_dev(ip[0], tmp.data_ptr(), rows * W, mode, s_ptr), "gray_of_plane")
+                ref2 = torch.empty_like(edge)
+                chk(lib.gh_sobel_u8_rows_dev(tmp.data_ptr(), ref2.data_ptr(), W, rows, 1, 1, s_ptr), "sobel")
+                torch.cuda.synchronize()
+                if not all(bool(torch.equal(o_, ref2)) for o_ in outs):
+                    print("bench.py: parity check FAILED in the fourth timed region (pass k in one launch != gray_of_plane + Sobel)", file=sys.stderr)
+                    return 3
+                check += "; pass k in one launch == gray_of_plane + Sobel"
+                del tmp, ref2
+            del edges, outs
 
         # outside the timed regions: the in-place reference-ABI kernel, and the copy ceiling of this GPU
         def time_kernel(fn, reps=30):
@@ -844,7 +876,7 @@ def main() -> int:
                     "repeats": {"ms_per_step": [round(v, 4) for v in rep_ms], "min": round(min(rep_ms), 4),
                                 "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4), "max": round(max(rep_ms), 4),
                                 "note": "the K-step bracket run again back to back; value / ms_per_step are the first entry"},
-                    "second_timed_region": other, "third_timed_region": sobel_alone,
+                    "second_timed_region": other, "third_timed_region": sobel_alone, "fourth_timed_region": pass_k,
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "host_enqueue_us_per_step": round(host_enqueue * 1e6 / args.steps, 1)})
         parallelism = "single GPU"

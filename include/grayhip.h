@@ -104,6 +104,15 @@ GH_API int gh_sobel_u8_dev(const uint8_t *src, uint8_t *dst, int width, int heig
 GH_API int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows,
                                 int top_is_border, int bottom_is_border, gh_stream_t stream);
 
+/* Pass k >= 2 of the reference's gray + Sobel driver loop (monolithic/src/main_with_sobel.c:51-62 applied to what pass k - 1 wrote, the
+ * replicated edge image (e, e, e)) in ONE kernel: src holds pass k - 1's edge plane and every byte goes through lum(e, e, e) -- `mode`
+ * arithmetic; not the identity, 13 grey levels move in IEEE mode -- on its way into the 3x3 window.  1 R + 1 W byte per pixel, where
+ * gh_gray_of_plane_dev + gh_sobel_u8_dev move 4.  Same band semantics and border rule as gh_sobel_u8_rows_dev; a halo row holds the
+ * neighbouring EDGE row (the kernel applies the luma to it as well). */
+GH_API int gh_sobel_of_gray_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, int mode, gh_stream_t stream);
+GH_API int gh_sobel_of_gray_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, int mode,
+                                        int top_is_border, int bottom_is_border, gh_stream_t stream);
+
 /* Fused RGB -> luma -> Sobel; the luma plane never touches HBM.  Same band semantics as above
  * (halo rows are RGB rows).  3 R + 1 W bytes per pixel.  Any width and any alignment: frames of 1024 columns and more run the
  * LDS-DMA ring kernel whatever their row pitch and base address, narrower ones register-staged strips / the per-pixel kernel. */
@@ -135,7 +144,9 @@ GH_API int gh_mean_gray_minmax_dev(const uint8_t *rgb, uint8_t *out_rgb, size_t 
                                    gh_stream_t stream);
 
 /* `passes` x (gray -> sobel -> replicate) on a device-resident interleaved image, reference
- * semantics (main_with_sobel.c:51-74).  gray_ws / edge_ws: width*height bytes of scratch each. */
+ * semantics (main_with_sobel.c:51-74).  gray_ws / edge_ws: width*height bytes of scratch each (two distinct planes: the edge planes of
+ * successive passes alternate between them, the last pass's ends in edge_ws).  Pass 1 is the fused kernel (4 B/px), every later pass
+ * gh_sobel_of_gray_u8_dev (2 B/px). */
 GH_API int gh_pipeline_gray_sobel_dev(uint8_t *img, int width, int height, int channels, int passes, int mode,
                                       uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream);
 
@@ -221,14 +232,19 @@ GH_API int gh_comm_set_step_form(gh_comm_t comm, int form);
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream);
 GH_API int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream);
+/*   sobel of gray (a later pass of the multi-pass pipeline): buf = the previous pass's EDGE rows in rows 1..rows, the halo is the
+ *   neighbour's raw edge row; the kernel applies lum(e, e, e) on load (gh_sobel_of_gray_u8_rows_dev) */
+GH_API int gh_sharded_sobel_of_gray_step_dev(gh_comm_t comm, uint8_t *edge_buf, uint8_t *edge, int width, int rows, int mode, gh_stream_t stream);
 /*   conv3x3: buf = RGB8 rows, the halo is one RGB row, dst = rows * width * 3 bytes (old/parallel_convolution.c:8-24 on a shard; the
  *   frame's own top / bottom edge keeps the zero border) */
 GH_API int gh_sharded_conv3x3_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *dst, int width, int rows, const int32_t kernel[9],
                                        int32_t norm, gh_stream_t stream);
 /* `passes` x (gray -> extract -> Sobel -> replicate) on a row shard, in place in rows 1..rows of img_buf ((rows + 2) rows of
  * width * channels bytes): monolithic/src/main_with_sobel.c:49-76 on a sharded frame.  Pass k + 1 filters what pass k wrote, so there
- * is ONE halo exchange per pass: an RGB row for pass 1 (fused kernel), a luma row -- lum(e, e, e) of the neighbour's edge row -- for
- * every later pass.  gray_ws: (rows + 2) * width bytes, edge_ws: rows * width bytes of scratch (the last pass's edge plane on return). */
+ * is ONE halo exchange per pass: an RGB row for pass 1 (fused kernel), the neighbour's raw edge row for every later pass (the plane Sobel
+ * applies lum(e, e, e) on load: one launch, 2 B/px per pass).  gray_ws and edge_ws: two distinct work planes of (rows + 2) * width bytes
+ * each (rows 1..rows = a plane, rows 0 / rows + 1 = its halo rows); the edge planes of successive passes alternate between them and
+ * the LAST pass's edge plane is in rows 1..rows of edge_ws (edge_ws + width) on return. */
 GH_API int gh_sharded_pipeline_gray_sobel_dev(gh_comm_t comm, uint8_t *img_buf, int width, int rows, int channels, int passes, int mode,
                                               uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream);
 /* Pipelined form for a STREAM of frames kept in a few such buffers: `cur` -- whose halo rows were requested by an

@@ -10,8 +10,12 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GRAYHIP_LIB") or os.path.join(_PKG_DIR, "lib", "libgrayhip.so")   # override: A/B builds
 REPO_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.environ.get("GRAYHIP_LIB") or os.path.join(_PKG_DIR, "lib", "libgrayhip.so")   # override: A/B builds
+# The measurement lab (`make probes`, -DGH_ENABLE_PROBES): the same library plus the kernel variants that lost their A/B, the
+# no-arithmetic probes and the GH_* tuning knobs that select them.  Never the product: tools/ and the variant-sweeping tests load it
+# through use_library(); the release library above reads none of those knobs.
+LAB_LIB_PATH = os.path.join(REPO_ROOT, "build_probes", "libgrayhip_probes.so")
 
 MODE_IEEE = 0
 MODE_FMA = 1
@@ -40,6 +44,8 @@ SIGNATURES = {
     "gh_gray_inplace_passes_dev": (C.c_int, [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sobel_u8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _stream]),
     "gh_sobel_u8_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_sobel_of_gray_u8_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _stream]),
+    "gh_sobel_of_gray_u8_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_gray_sobel_fused_rows_dev": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_extract_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
     "gh_replicate_plane_dev": (C.c_int, [_u8p, _u8p, C.c_size_t, C.c_int, _stream]),
@@ -73,6 +79,7 @@ SIGNATURES = {
     "gh_sharded_pipeline_gray_sobel_dev": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _stream]),
     "gh_sharded_fused_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
+    "gh_sharded_sobel_of_gray_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_step_pipelined_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_fused_stream_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _stream]),
     "gh_sharded_sobel_stream_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, _u8p, C.c_int, C.c_int, _stream]),
@@ -95,23 +102,51 @@ class GrayHipError(RuntimeError):
 
 
 _lib = None
+_opened = {}          # path -> typed CDLL
+
+
+def _open(path: str) -> C.CDLL:
+    lib = _opened.get(path)
+    if lib is None:
+        if not os.path.exists(path):
+            raise GrayHipError(
+                f"{path} is missing: build it with `make lib` / `make probes` (or __graft_entry__.build()); "
+                "there is no CPU fallback for the hot path")
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _opened[path] = lib
+    return lib
 
 
 def load() -> C.CDLL:
     """dlopen libgrayhip.so (no GPU work happens here) and type every exported symbol."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise GrayHipError(
-                f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
-                "there is no CPU fallback for the hot path")
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)     # AttributeError if the symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+class use_library:
+    """`with abi.use_library(abi.LAB_LIB_PATH):` -- every call of this package goes to another build of the library inside the block
+    (tests and tools that sweep kernel variants: the probe build).  Handles made by one library (communicators) must not be handed to
+    the other; device memory is the process's and may."""
+
+    def __init__(self, path: str):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        _lib = _open(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(rc: int, what: str = "") -> None:

@@ -262,7 +262,8 @@ int gh_comm_set_loopback(gh_comm_t comm, int mode)
 int gh_comm_set_step_form(gh_comm_t comm, int form)
 {
     GH_REQUIRE(comm, "null communicator");
-    GH_REQUIRE(form >= -1 && form <= 2, "form must be -1, 0, 1 or 2");
+    GH_REQUIRE(form >= -1 && form <= 2, "form must be -1, 1 or 2 (0 in probe builds)");
+    GH_REQUIRE(GH_LAB || form != 0, "form 0 (events) lost its A/B and exists in probe builds only (make probes)");
     Comm *c = static_cast<Comm *>(comm);
     c->step_form = form;
     forget_announced(c);
@@ -487,8 +488,8 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     //    (the launch alone: 29.3 / 50.4 / 96.0).
     //  1 serial: the exchange on the caller's stream in front of ONE launch -- no side stream, no events; the exchange (one row, ~11 us)
     //    is not hidden: 40.0 / 62.7 / 110.7 (round 2's default).
-    //  0 overlapped with events: exchange on the side stream || interior rows, then two one-row launches behind an event -- pays two
-    //    cross-queue event hand-overs (~20 us each on this runtime) and two extra launches: 58.2 / 66.9 / 116.7.
+    //  0 overlapped with events (probe builds only): exchange on the side stream || interior rows, then two one-row launches behind an event --
+    //    pays two cross-queue event hand-overs (~20 us each on this runtime) and two extra launches: 58.2 / 66.9 / 116.7.
     int form = c->step_form >= 0 ? c->step_form : GH_KNOB_INT("GH_SHARD_STEP_FORM", 2);
     if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
         GhHaloWait probe{};
@@ -517,6 +518,7 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
         if (rc != GH_OK) halo_flag_release(s, hw);
         return rc;
     }
+#ifdef GH_ENABLE_PROBES
     // the exchange reads rows 1 / rows (written by earlier work on s) and overwrites the halo rows the previous step read
     GH_HIP_TRY(hipEventRecord(c->ready, s));
     GH_HIP_TRY(hipStreamWaitEvent(c->side, c->ready, 0));
@@ -530,6 +532,9 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     }
     GH_HIP_TRY(hipStreamWaitEvent(s, c->landed, 0));
     return launch(0, rows, up < 0, down < 0);
+#else
+    return gh_set_error(GH_ERR_ARG, "GH_SHARD_STEP_FORM=%d: this library has forms 2 (halo flag) and 1 (serial)", form);
+#endif
 }
 
 // Pipelined form for a stream of frames held in a few buffers: the halo rows of `prefetch` (a frame that will be `cur`
@@ -750,7 +755,7 @@ int gh_sharded_sobel_stream_step_dev(gh_comm_t comm, uint8_t *cur_luma_buf, uint
     Comm *c = static_cast<Comm *>(comm);
     const size_t rb = (size_t)width;
     return sharded_stream_step(c, cur_luma_buf, next_luma_buf, rb, rows, (hipStream_t)stream,
-        [&](int tb, int bb, const GhHaloWait &hw) { return gh_sobel_rows_halo_wait(cur_luma_buf + rb, edge, width, rows, tb, bb, stream, &hw); },
+        [&](int tb, int bb, const GhHaloWait &hw) { return gh_sobel_rows_halo_wait(cur_luma_buf + rb, edge, width, rows, tb, bb, stream, &hw, 0); },
         [&] { return gh_sobel_u8_rows_dev(cur_luma_buf + rb, edge, width, rows, 1, 1, stream); },
         [&] { return gh_sharded_sobel_step_pipelined_dev(comm, cur_luma_buf, next_luma_buf, edge, width, rows, stream); });
 }
@@ -770,19 +775,32 @@ int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, i
     });
 }
 
-int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream)
+// luma: 0 = buf holds luma rows; 1 / 2 = buf holds the previous pass's EDGE rows and the kernel applies lum(e, e, e) on load (IEEE / FMA):
+// the halo row exchanged is then the neighbour's raw edge row
+static int sharded_sobel_step(gh_comm_t comm, uint8_t *plane_buf, uint8_t *edge, int width, int rows, int luma, gh_stream_t stream)
 {
     GH_REQUIRE(comm, "null communicator");
     GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
     if (width == 0 || rows == 0) return GH_OK;
-    GH_REQUIRE(luma_buf && edge, "null pointer");
+    GH_REQUIRE(plane_buf && edge, "null pointer");
     Comm *c = static_cast<Comm *>(comm);
     const size_t rb = (size_t)width;
-    return sharded_step(c, luma_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
-        return gh_sobel_u8_rows_dev(luma_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, tb, bb, stream);
+    return sharded_step(c, plane_buf, rb, rows, (hipStream_t)stream, [&](int first, int n, int tb, int bb) {
+        return gh_sobel_rows_halo_wait(plane_buf + (size_t)(first + 1) * rb, edge + (size_t)first * width, width, n, tb, bb, stream, nullptr, luma);
     }, [&](int tb, int bb, const GhHaloWait &hw) {
-        return gh_sobel_rows_halo_wait(luma_buf + rb, edge, width, rows, tb, bb, stream, &hw);
+        return gh_sobel_rows_halo_wait(plane_buf + rb, edge, width, rows, tb, bb, stream, &hw, luma);
     });
+}
+
+int gh_sharded_sobel_step_dev(gh_comm_t comm, uint8_t *luma_buf, uint8_t *edge, int width, int rows, gh_stream_t stream)
+{
+    return sharded_sobel_step(comm, luma_buf, edge, width, rows, 0, stream);
+}
+
+int gh_sharded_sobel_of_gray_step_dev(gh_comm_t comm, uint8_t *edge_buf, uint8_t *edge, int width, int rows, int mode, gh_stream_t stream)
+{
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
+    return sharded_sobel_step(comm, edge_buf, edge, width, rows, 1 + mode, stream);
 }
 
 // 3x3 convolution of a row shard (old/parallel_convolution.c:8-24 on a sharded frame): buf holds
@@ -805,37 +823,41 @@ int gh_sharded_conv3x3_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *dst, 
 // `passes` x (gray -> extract -> Sobel -> replicate) on a row shard (monolithic/src/main_with_sobel.c:49-76 on a sharded frame, SURVEY.md
 // section 8e row 4): pass k + 1 filters what pass k wrote, so the rows next to a shard edge depend on the neighbour's pass-k edge rows
 // -- ONE halo exchange per pass.  Pass 1 exchanges an RGB row and runs the fused kernel (the luma plane is dead after it, as in
-// gh_pipeline_gray_sobel_dev); pass k > 1 forms lum(e, e, e) of its own edge rows (not the identity: 13 grey levels move in IEEE mode),
-// exchanges one luma row and runs the plane Sobel.  img_buf: rows + 2 rows of width * channels bytes (rows 1..rows = the shard, in
-// place like the reference); gray_ws: (rows + 2) * width bytes; edge_ws: rows * width bytes (holds the last pass's edge plane on return).
+// gh_pipeline_gray_sobel_dev); pass k > 1 exchanges the neighbours' raw EDGE rows and runs the plane Sobel with lum(e, e, e) applied on
+// load (not the identity: 13 grey levels move in IEEE mode) -- one launch and 2 B/px per pass instead of a luma pass plus a Sobel pass.
+// The edge planes of successive passes alternate between the two work planes, each (rows + 2) rows of `width` bytes (rows 1..rows = the
+// plane, rows 0 / rows + 1 receive the neighbours' rows); the last pass writes edge_ws, whose rows 1..rows hold its edge plane on return.
+// img_buf: rows + 2 rows of width * channels bytes (rows 1..rows = the shard, in place like the reference).
 int gh_sharded_pipeline_gray_sobel_dev(gh_comm_t comm, uint8_t *img_buf, int width, int rows, int channels, int passes, int mode,
                                        uint8_t *gray_ws, uint8_t *edge_ws, gh_stream_t stream)
 {
     GH_REQUIRE(comm, "null communicator");
     GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
     GH_REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4");
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
     if (passes < 1) passes = 1;   // main_with_sobel.c:44-45
     if (width == 0 || rows == 0) return GH_OK;
-    GH_REQUIRE(img_buf && gray_ws && edge_ws, "null pointer");
+    GH_REQUIRE(img_buf && gray_ws && edge_ws && gray_ws != edge_ws, "null or aliased work planes");
     const size_t npix = (size_t)width * rows, pitch = (size_t)width * channels;
-    uint8_t *shard = img_buf + pitch, *gray = gray_ws + width;
+    uint8_t *shard = img_buf + pitch;
+    // pass p (0-based) writes plane[(passes - 1 - p) & 1]: the last pass lands in edge_ws
+    uint8_t *const plane[2] = {edge_ws, gray_ws};
     for (int p = 0; p < passes; ++p) {
+        uint8_t *out = plane[(passes - 1 - p) & 1], *in = plane[(passes - p) & 1];
         int rc;
         if (p == 0 && channels >= 3) {
-            if ((rc = gh_sharded_fused_step_dev(comm, img_buf, edge_ws, width, rows, channels, mode, stream))) return rc;
-            continue;
-        } else if (p == 0) {
-            rc = gh_gray_rgb8_to_plane_dev(shard, gray, npix, channels, mode, stream);      // channels 1 / 2: the plane is channel 0
-        } else if (channels >= 3) {
-            rc = gh_gray_of_plane_dev(edge_ws, gray, npix, mode, stream);
+            rc = gh_sharded_fused_step_dev(comm, img_buf, out + width, width, rows, channels, mode, stream);
+        } else if (p == 0) {                       // channels 1 / 2: the plane is channel 0, filtered as it is by every pass
+            if ((rc = gh_gray_rgb8_to_plane_dev(shard, in + width, npix, channels, mode, stream))) return rc;
+            rc = gh_sharded_sobel_step_dev(comm, in, out + width, width, rows, stream);
+        } else if (channels >= 3) {                // the image holds (e, e, e) now: its luma is lum(e, e, e), applied on load
+            rc = gh_sharded_sobel_of_gray_step_dev(comm, in, out + width, width, rows, mode, stream);
         } else {
-            hipError_t e = hipMemcpyAsync(gray, edge_ws, npix, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-            rc = e == hipSuccess ? GH_OK : gh_set_error(GH_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+            rc = gh_sharded_sobel_step_dev(comm, in, out + width, width, rows, stream);
         }
         if (rc) return rc;
-        if ((rc = gh_sharded_sobel_step_dev(comm, gray_ws, edge_ws, width, rows, stream))) return rc;
     }
-    return gh_replicate_plane_dev(edge_ws, shard, npix, channels, stream);
+    return gh_replicate_plane_dev(edge_ws + width, shard, npix, channels, stream);
 }
 
 }  // extern "C"

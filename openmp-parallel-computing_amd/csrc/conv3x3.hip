@@ -358,7 +358,10 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
     // trunc(acc / norm) == trunc(-acc / -norm): normalise to a positive divisor
     const int sgn = norm < 0 ? -1 : 1;
     const long long wb = (long long)width * 3;
-    const bool exact = (long long)sgn * norm <= 4096 && ksum * 255 < (1ll << 24) && !getenv("GH_CONV_IMPL");     // conditions of the f32 forms
+    bool exact = (long long)sgn * norm <= 4096 && ksum * 255 < (1ll << 24);     // conditions of the f32 forms
+#ifdef GH_ENABLE_PROBES
+    if (getenv("GH_CONV_IMPL")) exact = false;      // probe builds: GH_CONV_IMPL=px sends every frame to the per-pixel integer kernel
+#endif
     const bool aligned = (wb % 16 == 0) && gh_aligned16(src) && gh_aligned16(dst);
     const int ylo = top_is_border ? 0 : -1, yhi = bottom_is_border ? height - 1 : height;   // readable input rows, relative to the band
     TapsF t;
@@ -369,7 +372,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         t.half_inv = 0.5f / n;
     }
     // LDS-DMA ring kernel: any row of 1024 bytes and more, any alignment (GH_CONV_DMA=0: the register-staged strips, aligned frames only)
-    if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_TUNE_INT("GH_CONV_DMA", 1)) {
+    if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_LAB_INT("GH_CONV_DMA", 1)) {
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);
         // Band height: 16 rows.  (This kernel had inherited the Sobel kernels' 64 / 32 / 16 rule untested.  Measured, tools/sweep.py r2_bb, bc:
@@ -380,17 +383,17 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         // apart fall on many channel phases where 16 x 48 KiB fall on four -- beat 16 on every shape tried: 16384^2 0.2851 vs 0.2956 ms
         // (70.6 % vs 68.1 %), 16370 x 16384 0.3287 vs 0.3379, 16384 x 4096 0.0759 vs 0.0779, 7680 x 4320 0.0440 vs 0.0455, 12288^2 equal; 28 /
         // 34 / 40 / 64 rows lose 3-7 %.  Where 22-row starts would alias and 16-row ones do not (stream_core::prefer_short_bands) 16 stays.
-        int R = GH_TUNE_INT("GH_CONV_R", 0);
-        if (R <= 0) R = (height >= 22 && !(GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(wb, 22, 16))) ? 22 : 16;
+        int R = GH_LAB_INT("GH_CONV_R", 0);
+        if (R <= 0) R = (height >= 22 && !(GH_LAB_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(wb, 22, 16))) ? 22 : 16;
         stream_core::BandPlan plan = stream_core::make_band_plan(height, R, -1, 0, -1, 0);
         // pairs-per-XCD dispatch order (8): 0.290 ms against 0.293 (band-per-XCD) / 0.294 (plain) on 16384^2, ahead on 16368 / 16370 too
-        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x, gh_num_xcd());
+        plan.order = stream_core::sanitize_order(GH_LAB_INT("GH_CONV_ORDER", 8) % 1000, plan.bands, groups_x, gh_num_xcd());
         const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         const int unal = aligned ? 0 : ((wb % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
         const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
         // regular-band form: bands whose R + 2 input rows are whole chunks of 6 and into which the rows split (16- and 64-row bands)
-        const bool reg = GH_TUNE_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
+        const bool reg = GH_LAB_INT("GH_CONV_REG", 1) && (R + 2) % 6 == 0 && R >= 16 && height >= R && plan.order < 1000 &&
                          !stream_core::shifted_band_overflows(groups_x, height, R, 5, gh_num_cu());
         gh_note_kernel(reg ? (unal ? "k_conv3x3_dma regular unaligned" : "k_conv3x3_dma regular") : (unal ? "k_conv3x3_dma unaligned" : "k_conv3x3_dma"));
         if (reg && unal == 0) k_conv3x3_dma<3, 0, 1><<<g, b, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan, t);
@@ -409,14 +412,14 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         // 64-row bands measured 5-10 % faster than 32 on MI355X), else 32, else 16
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);
-        int R = GH_TUNE_INT("GH_CONV_R", 0);
+        int R = GH_LAB_INT("GH_CONV_R", 0);
         if (R != 16 && R != 32 && R != 64) {
             const long long nb64 = (long long)groups_x * ((height + 63) / 64), nb32 = (long long)groups_x * ((height + 31) / 32);
             R = nb64 >= 2 * gh_num_cu() ? 64 : (nb32 >= 2 * gh_num_cu() ? 32 : 16);
         }
         stream_core::BandPlan plan{};
         plan.bands = (height + R - 1) / R;
-        plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x, gh_num_xcd());   // band-per-XCD, as the fused kernel
+        plan.order = stream_core::sanitize_order(GH_LAB_INT("GH_CONV_ORDER", 6) % 1000, plan.bands, groups_x, gh_num_xcd());   // band-per-XCD, as the fused kernel
         const long long nb = stream_core::plan_grid(plan, groups_x);
         GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
         if (R == 64) k_conv3x3_stream<64, 2><<<(unsigned)nb, stream_core::BLOCK, 0, s>>>(src, dst, (int)wb, height, ylo, yhi, groups_x, plan.order, t);

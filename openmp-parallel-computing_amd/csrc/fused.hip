@@ -13,8 +13,10 @@
 //   k_fused_stream      narrow frames (or GH_FUSED_DMA=0): the same strip streaming, rows staged through registers
 //                       (coalesced dwordx4 loads -> ds_write -> ds_read de-interleave).
 //   k_gray_sobel_fused  the LDS-tile form (sobel_tile.h); GH_FUSED_IMPL=tile
-#include "sobel_tile.h"
 #include "stream_core.h"
+#ifdef GH_ENABLE_PROBES
+#include "sobel_tile.h"
+#endif
 
 #include <type_traits>
 
@@ -24,33 +26,14 @@
 
 namespace {
 
+#ifdef GH_ENABLE_PROBES
 using namespace sobel_tile;
+#endif
 using stream_core::row_readable;
 using stream_core::BandPlan;
 using stream_core::make_band_plan;
 
-// luma of two pixels as integer-valued floats (packed f32: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32):
-// trunc(y) == (float)(unsigned char)y for 0 <= y <= 255; same arithmetic as gh_luma, minus the float->int->float
-// round trip.  IEEE mode must not be contracted; the FMA mode uses explicit fused multiply-adds.
-template <int MODE>
-__device__ __forceinline__ stream_core::f32x2 luma_f2(stream_core::f32x2 r, stream_core::f32x2 g, stream_core::f32x2 b)
-{
-#pragma clang fp contract(off)
-    using stream_core::f32x2;
-    const f32x2 cr = {0.299f, 0.299f}, cg = {0.587f, 0.587f}, cb = {0.114f, 0.114f};
-    f32x2 y;
-    if (MODE == GH_MODE_FMA) {
-        f32x2 t = cg * g;
-        t = __builtin_elementwise_fma(cr, r, t);
-        y = __builtin_elementwise_fma(cb, b, t);
-    } else {
-        const f32x2 s = cr * r + cg * g;
-        y = s + cb * b;
-    }
-    y.x = stream_core::opaque(__builtin_truncf(y.x));
-    y.y = stream_core::opaque(__builtin_truncf(y.y));
-    return y;
-}
+using stream_core::luma_f2;      // (stream_core.h: shared with the plane Sobel's luma-on-load form)
 
 template <int MODE>
 __device__ __forceinline__ float luma_f(uint32_t r, uint32_t g, uint32_t b)
@@ -232,39 +215,6 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_fused_px_cols(const uint
         edge[(size_t)y * w + x] = (uint8_t)out;
     }
 }
-
-template <int MODE, int CH>
-__device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
-{
-    uint32_t lum[16];
-    if (CH == 3) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(p);
-        const uint4 a = q[0], b = q[1], c = q[2];
-        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int o = 3 * i;
-            lum[i] = gh_luma<MODE>(gh_byte(w[o >> 2], o & 3), gh_byte(w[(o + 1) >> 2], (o + 1) & 3),
-                                   gh_byte(w[(o + 2) >> 2], (o + 2) & 3));
-        }
-    } else {
-        const uint4 *q = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 v = q[j];
-            const uint32_t px[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lum[4 * j + k] = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
-        }
-    }
-    uint4 o;
-    o.x = lum[0] | (lum[1] << 8) | (lum[2] << 16) | (lum[3] << 24);
-    o.y = lum[4] | (lum[5] << 8) | (lum[6] << 16) | (lum[7] << 24);
-    o.z = lum[8] | (lum[9] << 8) | (lum[10] << 16) | (lum[11] << 24);
-    o.w = lum[12] | (lum[13] << 8) | (lum[14] << 16) | (lum[15] << 24);
-    return o;
-}
-
 
 // ---- LDS-DMA form (RGB8 / RGBA8, width >= 1024): rows go HBM -> LDS directly (global_load_lds_dwordx4), D rows deep -----------
 // The register-staged kernel above holds C rows of loads in VGPRs (24 + 8 registers at C = 2) and pays three ds_write per
@@ -468,6 +418,41 @@ void k_fused_dma(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, in
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
+#ifdef GH_ENABLE_PROBES
+// ---- the LDS-tile form (sobel_tile.h): the first version measured (0.232 ms against 0.184); GH_FUSED_IMPL=tile in probe builds ----
+template <int MODE, int CH>
+__device__ __forceinline__ uint4 luma_chunk(const uint8_t *__restrict__ p)
+{
+    uint32_t lum[16];
+    if (CH == 3) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+        const uint4 a = q[0], b = q[1], c = q[2];
+        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = 3 * i;
+            lum[i] = gh_luma<MODE>(gh_byte(w[o >> 2], o & 3), gh_byte(w[(o + 1) >> 2], (o + 1) & 3),
+                                   gh_byte(w[(o + 2) >> 2], (o + 2) & 3));
+        }
+    } else {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = q[j];
+            const uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lum[4 * j + k] = gh_luma<MODE>(gh_byte(px[k], 0), gh_byte(px[k], 1), gh_byte(px[k], 2));
+        }
+    }
+    uint4 o;
+    o.x = lum[0] | (lum[1] << 8) | (lum[2] << 16) | (lum[3] << 24);
+    o.y = lum[4] | (lum[5] << 8) | (lum[6] << 16) | (lum[7] << 24);
+    o.z = lum[8] | (lum[9] << 8) | (lum[10] << 16) | (lum[11] << 24);
+    o.w = lum[12] | (lum[13] << 8) | (lum[14] << 16) | (lum[15] << 24);
+    return o;
+}
+
+
 template <int MODE, int CH>
 __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ edge, int w,
                                                             int rows, int tiles_x, int zero_top, int zero_bot)
@@ -493,6 +478,8 @@ __global__ __launch_bounds__(BLOCK) void k_gray_sobel_fused(const uint8_t *__res
 
     compute_tile(tile, edge, w, rows, x0, y0, zero_top, zero_bot);
 }
+
+#endif   // GH_ENABLE_PROBES
 
 // launch arguments of k_fused_dma, and the channel / mode dispatch
 struct DmaLaunch {
@@ -522,6 +509,8 @@ extern "C" int gh_gray_sobel_fused_rows_dev(const uint8_t *rgb, uint8_t *edge, i
 
 // hw != nullptr: the halo-flag form of the sharded step (gh_common.h) -- only the LDS-DMA ring kernel carries the wait; a frame that
 // would run another form is refused with GH_NO_FLAG_FORM before anything is launched.
+// GH_LAB_INT knobs are compile-time constants in the release library (gh_common.h); what they select beyond their defaults -- other ring
+// depths, store / load policies, the no-arithmetic probes, the LDS-tile form, tapered band plans -- exists in probe builds only.
 int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode, int top_is_border,
                             int bottom_is_border, gh_stream_t stream, const GhHaloWait *hw)
 {
@@ -547,24 +536,47 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
     // (unaligned strips need ws >= 1024: then every strip is full -- the last one is shifted left -- and the pixel right of
     //  column ws - 1 arrives through lane 63's halo load; a ragged last strip would need column ws from beyond its loads)
     // The LDS-DMA kernel takes any width >= 1024 and any base alignment (see sobel.hip: DMA pieces need no alignment on the
-    // global side, every strip is full); GH_FUSED_DMA_UNALIGNED=0 sends unaligned frames to the register-staged strips + tail.
-    const int dma_knob = GH_TUNE_INT("GH_FUSED_DMA", -1);      // ring depth D (0 = register-staged kernel, -1 = auto)
-    const bool dma_ok = dma_knob != 0 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 1));
+    // global side, every strip is full).
+    const int dma_knob = GH_LAB_INT("GH_FUSED_DMA", -1);      // ring depth D (-1 = by grid size; probe builds: 0 = register-staged kernel, 2 / 3 / 4)
+    const int dma_unal = GH_LAB_INT("GH_FUSED_DMA_UNALIGNED", 2);    // 2 aligned-down pieces (UNAL), 1 pieces from the strip's own address, 0 strips + tail
+    const bool dma_ok = dma_knob != 0 && width >= stream_core::STRIP_PX && (aligned || dma_unal);
+    bool use_tile = false;
+#ifdef GH_ENABLE_PROBES
     static const bool use_tile_env = [] { const char *e = getenv("GH_FUSED_IMPL"); return e && strcmp(e, "tile") == 0; }();
-    if (hw && (!dma_ok || (use_tile_env && aligned))) return GH_NO_FLAG_FORM;
+    use_tile = use_tile_env && aligned;
+#endif
+    if (hw && (!dma_ok || use_tile)) return GH_NO_FLAG_FORM;
     if (hw && hw->pad) return GH_OK;             // probe: the LDS-DMA ring kernel will run
-    if (!aligned && !dma_ok && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_TUNE_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
+    if (!aligned && !dma_ok && (ws < stream_core::STRIP_PX || (long long)width * rows < GH_LAB_INT("GH_FUSED_UNALIGNED_MIN_PX", 1 << 20))) {
         gh_note_kernel("k_fused_px_cols");
         launch_px_cols(0);
         GH_LAUNCH_CHECK();
         return GH_OK;
     }
-    const bool use_tile = use_tile_env && aligned;
-    if (!use_tile) {
-        const int variant = GH_TUNE_INT("GH_FUSED_VARIANT", 0);   // tuning knob
-        const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = ((dma_ok ? width : ws) + span - 1) / span;
-        const unsigned b = stream_core::BLOCK;
+#ifdef GH_ENABLE_PROBES
+    if (use_tile) {
+        const int tiles_x = (width + TW - 1) / TW;
+        const int tiles_y = (rows + TH - 1) / TH;
+        const long long nt = (long long)tiles_x * tiles_y;
+        GH_REQUIRE(nt < (1ll << 31), "frame too large for one launch");
+        const unsigned grid = (unsigned)nt;
+        gh_note_kernel("k_gray_sobel_fused");
+        if (channels == 3) {
+            if (mode == GH_MODE_FMA) k_gray_sobel_fused<GH_MODE_FMA, 3><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+            else k_gray_sobel_fused<GH_MODE_IEEE, 3><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+        } else {
+            if (mode == GH_MODE_FMA) k_gray_sobel_fused<GH_MODE_FMA, 4><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+            else k_gray_sobel_fused<GH_MODE_IEEE, 4><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+        }
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+#endif
+    const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
+    const int groups_x = ((dma_ok ? width : ws) + span - 1) / span;
+    const unsigned b = stream_core::BLOCK;
+    if (!dma_ok) {
+        // register-staged strips: frames narrower than 1024 columns (rolling prefetch, two rows deep)
 #define GH_FUSED_LAUNCH(R_, C_, RL_)                                                                                         \
         do {                                                                                                              \
             const long long nb = (long long)groups_x * ((rows + (R_) - 1) / (R_));                                         \
@@ -578,94 +590,18 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
                 else k_fused_stream<GH_MODE_IEEE, 4, R_, C_, RL_><<<g, b, 0, s>>>(rgb, edge, width, rows, groups_x, zt, zb, ws);                     \
             }                                                                                                             \
         } while (0)
-        // LDS-DMA ring kernel.  Tuning found on MI355X (tools/ab_fused.py, 16384-wide frames):
-        //  * band height 64 is the sweet spot whenever it still gives every CU a workgroup (69-73 % of 8 TB/s for 4096 ..
-        //    16384-row frames); 32- and 128-row bands are 5-15 % slower at the same frame, 16-row bands pay 12.5 % halo rows;
-        //  * band-per-XCD dispatch order (order 6: XCD x owns the bands k = x mod 8 with all their column groups) is 0.5-2.5 %
-        //    faster than the plain band-major order on every frame shape and shard size tried (16384^2: 72.9 % vs 72.1 %);
-        //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
-        //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
-        int dma = dma_knob;
-        if (dma_ok) {
-            int rd = GH_TUNE_INT("GH_FUSED_DMA_R", 0);
-            if (rd <= 0) {
-                rd = stream_core::fused_band_rows(groups_x, rows, (long long)width * channels, gh_num_cu(), GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0,
-                                                  hw != nullptr && GH_TUNE_INT("GH_SHARD_BAND_RULE", 1) != 0);
-            }
-            const int sp = GH_TUNE_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores (production); other values: probes
-            const int R_ = rd;
-            // taper knobs: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2
-            BandPlan plan = make_band_plan(rows, R_, GH_TUNE_INT("GH_FUSED_DMA_N0", -1), GH_TUNE_INT("GH_FUSED_DMA_R1", 0),
-                                                 GH_TUNE_INT("GH_FUSED_DMA_N1", -1), GH_TUNE_INT("GH_FUSED_DMA_R2", 0));
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_FUSED_DMA_ORDER", 6), plan.bands, groups_x, gh_num_xcd());
-            
-            GH_REQUIRE(stream_core::plan_grid(plan, groups_x) < (1ll << 31), "frame too large for one launch");
-            const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);
-            int pad_kb = GH_TUNE_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU
-            if (dma < 0) {
-                const bool big = g > 2u * gh_num_cu();
-                dma = big ? 2 : 3;
-                if (pad_kb < 0) pad_kb = big ? 30 : 0;               // 24.7 KiB ring + 30 KiB > 160 KiB / 3: two per CU
-            }
-            if (pad_kb < 0) pad_kb = 0;
-            const size_t pad = (size_t)pad_kb * 1024;
-            const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s, hw ? *hw : GhHaloWait{}};
-            // frames with unaligned rows: GH_FUSED_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_fused_dma, UNAL), 1 = pieces from
-            // the strip's own unaligned address, 0 = register-staged strips + column tail
-            const int unal = aligned || GH_TUNE_INT("GH_FUSED_DMA_UNALIGNED", 2) < 2 || dma == 4 ? 0
-                             : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
-            // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
-            // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/sweep.py r2_ba); aligned frames only
-            const int reg_knob = GH_TUNE_INT("GH_FUSED_REG", 1);     // 2: also tall bands whose R + 2 rows are whole chunks of 6 (experiment, NOTES.md R3.5)
-            const bool reg = reg_knob && sp == 2 && dma == 3 && unal == 0 && (R_ == 16 || (reg_knob == 2 && (R_ + 2) % 6 == 0)) && rows >= R_ && plan.n[1] == 0 &&
-                             plan.order < 1000 && !stream_core::shifted_band_overflows(groups_x, rows, R_, 3, gh_num_cu());
-            gh_note_kernel(reg ? (R_ == 16 ? "k_fused_dma regular R=16" : "k_fused_dma regular") : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
-            if (reg) {
-                launch_fused_dma<3, 2, 0, 1>(L);
-            } else if (sp == 2 && unal) {
-                if (dma == 2) { if (unal == 1) launch_fused_dma<2, 2, 1>(L); else launch_fused_dma<2, 2, 2>(L); }
-                else { if (unal == 1) launch_fused_dma<3, 2, 1>(L); else launch_fused_dma<3, 2, 2>(L); }
-            } else if (sp == 2) {               // production: nontemporal output stores
-                if (dma == 2) launch_fused_dma<2, 2>(L);
-                else if (dma == 4) launch_fused_dma<4, 2>(L);
-                else launch_fused_dma<3, 2>(L);
-            } else {
-#ifdef GH_ENABLE_PROBES
-                // SP = 100 * (load policy + 1) + 10 * probe + store policy -- see k_fused_dma; RGB8 only
-                switch (dma * 1000 + sp) {
-                case 2000: launch_fused_dma<2, 0>(L); break;
-                case 2001: launch_fused_dma<2, 1>(L); break;
-                case 2102: launch_fused_dma<2, 102>(L); break;
-                case 2302: launch_fused_dma<2, 302>(L); break;
-                case 2402: launch_fused_dma<2, 402>(L); break;
-                case 2502: launch_fused_dma<2, 502>(L); break;
-                case 3000: launch_fused_dma<3, 0>(L); break;
-                case 3001: launch_fused_dma<3, 1>(L); break;
-                case 3010: launch_fused_dma<3, 10>(L); break;
-                case 3012: launch_fused_dma<3, 12>(L); break;
-                case 3022: launch_fused_dma<3, 22>(L); break;
-                case 4000: launch_fused_dma<4, 0>(L); break;
-                case 4001: launch_fused_dma<4, 1>(L); break;
-                default: GH_REQUIRE(false, "unknown GH_FUSED_DMA / GH_FUSED_DMA_ST probe combination");
-                }
-#else
-                GH_REQUIRE(false, "GH_FUSED_DMA_ST probes need a library built with -DGH_ENABLE_PROBES (make HIPFLAGS_EXTRA=-DGH_ENABLE_PROBES)");
-#endif
-            }
-            GH_LAUNCH_CHECK();
-            return GH_OK;
-        }
         gh_note_kernel(ws < width ? "k_fused_stream + k_fused_px_cols" : "k_fused_stream");
-        int pick = variant;
+        int pick = GH_LAB_INT("GH_FUSED_VARIANT", 0);
         if (pick == 0) {
             const long long nb64 = (long long)groups_x * ((rows + 63) / 64), nb32 = (long long)groups_x * ((rows + 31) / 32);
             pick = nb64 >= 4 * gh_num_cu() ? 64 : (nb32 >= 4 * gh_num_cu() ? 32 : 16);     // >= 4 workgroups per CU
         }
         switch (pick) {
         case 64: GH_FUSED_LAUNCH(64, 2, 1); break;
-        case 32: GH_FUSED_LAUNCH(32, 2, 1); break;
         case 16: GH_FUSED_LAUNCH(16, 2, 1); break;
-        case 1: GH_FUSED_LAUNCH(32, 2, 0); break;      // tuning: chunked loads instead of the rolling prefetch
+#ifdef GH_ENABLE_PROBES
+        case 1: GH_FUSED_LAUNCH(32, 2, 0); break;      // chunked loads instead of the rolling prefetch
+#endif
         default: GH_FUSED_LAUNCH(32, 2, 1); break;
         }
 #undef GH_FUSED_LAUNCH
@@ -676,17 +612,77 @@ int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int ro
         }
         return GH_OK;
     }
-    const int tiles_x = (width + TW - 1) / TW;
-    const int tiles_y = (rows + TH - 1) / TH;
-    const long long nt = (long long)tiles_x * tiles_y;
-    GH_REQUIRE(nt < (1ll << 31), "frame too large for one launch");
-    const unsigned grid = (unsigned)nt;
-    if (channels == 3) {
-        if (mode == GH_MODE_FMA) k_gray_sobel_fused<GH_MODE_FMA, 3><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
-        else k_gray_sobel_fused<GH_MODE_IEEE, 3><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+
+    // ---- LDS-DMA ring kernel.  Tuning found on MI355X (tools/ab_fused.py, 16384-wide frames):
+    //  * band height 64 is the sweet spot whenever it still gives every CU a workgroup (69-73 % of 8 TB/s for 4096 ..
+    //    16384-row frames); 32- and 128-row bands are 5-15 % slower at the same frame, 16-row bands pay 12.5 % halo rows;
+    //  * band-per-XCD dispatch order (order 6: XCD x owns the bands k = x mod 8 with all their column groups) is 0.5-2.5 %
+    //    faster than the plain band-major order on every frame shape and shard size tried (16384^2: 72.9 % vs 72.1 %);
+    //  * two resident workgroups per CU beat three (fewer row streams in flight at once: 71.9 % vs 69.5 %), so a large
+    //    launch uses the 2-deep ring plus an unused dynamic-LDS pad that caps residency at two.
+    int dma = dma_knob;
+    int rd = GH_LAB_INT("GH_FUSED_DMA_R", 0);
+    if (rd <= 0)
+        rd = stream_core::fused_band_rows(groups_x, rows, (long long)width * channels, gh_num_cu(), GH_LAB_INT("GH_BAND_ALIAS_RULE", 1) != 0,
+                                          hw != nullptr && GH_LAB_INT("GH_SHARD_BAND_RULE", 1) != 0);
+    const int sp = GH_LAB_INT("GH_FUSED_DMA_ST", 2);       // 2 = nontemporal stores; other values: probes
+    const int R_ = rd;
+    // (taper knobs, probe builds: GH_FUSED_DMA_N0 bands of R_, then GH_FUSED_DMA_N1 of GH_FUSED_DMA_R1, the rest GH_FUSED_DMA_R2)
+    BandPlan plan = make_band_plan(rows, R_, GH_LAB_INT("GH_FUSED_DMA_N0", -1), GH_LAB_INT("GH_FUSED_DMA_R1", 0),
+                                         GH_LAB_INT("GH_FUSED_DMA_N1", -1), GH_LAB_INT("GH_FUSED_DMA_R2", 0));
+    plan.order = stream_core::sanitize_order(GH_LAB_INT("GH_FUSED_DMA_ORDER", 6), plan.bands, groups_x, gh_num_xcd());
+    GH_REQUIRE(stream_core::plan_grid(plan, groups_x) < (1ll << 31), "frame too large for one launch");
+    const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);
+    int pad_kb = GH_LAB_INT("GH_FUSED_DMA_PAD_KB", -1);    // unused dynamic LDS: caps the workgroups resident per CU
+    if (dma < 0) {
+        const bool big = g > 2u * gh_num_cu();
+        dma = big ? 2 : 3;
+        if (pad_kb < 0) pad_kb = big ? 30 : 0;               // 24.7 KiB ring + 30 KiB > 160 KiB / 3: two per CU
+    }
+    if (pad_kb < 0) pad_kb = 0;
+    const size_t pad = (size_t)pad_kb * 1024;
+    const DmaLaunch L{rgb, edge, width, rows, groups_x, plan, zt, zb, channels, mode, g, pad, s, hw ? *hw : GhHaloWait{}};
+    // frames with unaligned rows: aligned-down pieces, landing dword-shifted (1) or byte-shifted + v_alignbyte (2); 0: aligned, or (probe
+    // builds, GH_FUSED_DMA_UNALIGNED=1) pieces from the strip's own unaligned address
+    const int unal = aligned || dma_unal < 2 || dma == 4 ? 0
+                     : (((long long)width * channels % 4 == 0 && ((uintptr_t)rgb & 3) == 0) ? 1 : 2);
+    // regular-band form (see k_sobel_dma): 16-row bands whose rows split evenly -- the mid-size and small frames, 0-5 % there
+    // (3840 x 2160 0.0150 vs 0.0157 ms, 1920 x 1088 0.0136 vs 0.0143, 8192 x 2048 0.0176 vs 0.0183; tools/sweep.py r2_ba); aligned frames only
+    const int reg_knob = GH_LAB_INT("GH_FUSED_REG", 1);     // (2, probe builds: also tall bands whose R + 2 rows are whole chunks of 6, NOTES.md R3.5)
+    const bool reg = reg_knob && sp == 2 && dma == 3 && unal == 0 && (R_ == 16 || (reg_knob == 2 && (R_ + 2) % 6 == 0)) && rows >= R_ && plan.n[1] == 0 &&
+                     plan.order < 1000 && !stream_core::shifted_band_overflows(groups_x, rows, R_, 3, gh_num_cu());
+    gh_note_kernel(reg ? (R_ == 16 ? "k_fused_dma regular R=16" : "k_fused_dma regular") : (unal ? (dma == 2 ? "k_fused_dma D=2 unaligned" : "k_fused_dma D=3 unaligned") : (dma == 2 ? "k_fused_dma D=2" : (dma == 4 ? "k_fused_dma D=4" : "k_fused_dma D=3"))));
+    if (reg) {
+        launch_fused_dma<3, 2, 0, 1>(L);
+    } else if (sp == 2 && unal) {
+        if (dma == 2) { if (unal == 1) launch_fused_dma<2, 2, 1>(L); else launch_fused_dma<2, 2, 2>(L); }
+        else { if (unal == 1) launch_fused_dma<3, 2, 1>(L); else launch_fused_dma<3, 2, 2>(L); }
+    } else if (sp == 2 && dma != 4) {   // what ships: nontemporal output stores, ring depth 2 (large grids) or 3
+        if (dma == 2) launch_fused_dma<2, 2>(L);
+        else launch_fused_dma<3, 2>(L);
     } else {
-        if (mode == GH_MODE_FMA) k_gray_sobel_fused<GH_MODE_FMA, 4><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
-        else k_gray_sobel_fused<GH_MODE_IEEE, 4><<<grid, BLOCK, 0, s>>>(rgb, edge, width, rows, tiles_x, zt, zb);
+#ifdef GH_ENABLE_PROBES
+        // SP = 100 * (load policy + 1) + 10 * probe + store policy -- see k_fused_dma; RGB8 only
+        switch (dma * 1000 + sp) {
+        case 4002: launch_fused_dma<4, 2>(L); break;
+        case 2000: launch_fused_dma<2, 0>(L); break;
+        case 2001: launch_fused_dma<2, 1>(L); break;
+        case 2102: launch_fused_dma<2, 102>(L); break;
+        case 2302: launch_fused_dma<2, 302>(L); break;
+        case 2402: launch_fused_dma<2, 402>(L); break;
+        case 2502: launch_fused_dma<2, 502>(L); break;
+        case 3000: launch_fused_dma<3, 0>(L); break;
+        case 3001: launch_fused_dma<3, 1>(L); break;
+        case 3010: launch_fused_dma<3, 10>(L); break;
+        case 3012: launch_fused_dma<3, 12>(L); break;
+        case 3022: launch_fused_dma<3, 22>(L); break;
+        case 4000: launch_fused_dma<4, 0>(L); break;
+        case 4001: launch_fused_dma<4, 1>(L); break;
+        default: GH_REQUIRE(false, "unknown GH_FUSED_DMA / GH_FUSED_DMA_ST probe combination");
+        }
+#else
+        return gh_set_error(GH_ERR_ARG, "unreachable: the release library has ring depths 2 / 3 and one store policy");
+#endif
     }
     GH_LAUNCH_CHECK();
     return GH_OK;

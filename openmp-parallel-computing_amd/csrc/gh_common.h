@@ -62,15 +62,16 @@ struct GhHaloWait {
 constexpr int GH_NO_FLAG_FORM = -100;      // internal: this frame shape runs a kernel form without the flag wait (narrow frames, per-pixel kernels)
 int gh_fused_rows_halo_wait(const uint8_t *rgb, uint8_t *edge, int width, int rows, int channels, int mode, int top_is_border,
                             int bottom_is_border, gh_stream_t stream, const GhHaloWait *hw);
+// luma: 0 = the plane as it is; 1 / 2 = every byte through lum(e, e, e) on load, IEEE / FMA arithmetic (pass k >= 2 of the driver loop)
 int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border, gh_stream_t stream,
-                            const GhHaloWait *hw);
+                            const GhHaloWait *hw, int luma);
 
 static inline bool gh_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Topology the launch rules work with: the CU and XCD counts of the initialised device (gh_init reads them; shim.hip).  The rules were
 // measured on an MI355X in SPX mode -- 256 CUs in 8 XCDs, the values before initialisation -- and are written in multiples of the CU count,
-// so a partitioned device (CPX: 32 CUs, one XCD) gets plans sized for what it has.  GH_NUM_CU_OVERRIDE (environment): pretend another CU
-// count (launch-rule experiments).  The workgroup -> band mappings that interleave over XCDs (band_of_block) assume 8 dispatch queues;
+// so a partitioned device (CPX: 32 CUs, one XCD) gets plans sized for what it has.  GH_NUM_CU_OVERRIDE (environment, probe builds): pretend
+// another CU count (launch-rule experiments).  The workgroup -> band mappings that interleave over XCDs (band_of_block) assume 8 dispatch queues;
 // with another XCD count they are still permutations -- every band is processed exactly once -- only the locality they aim at is lost.
 constexpr int GH_REF_NUM_CU = 256, GH_REF_NUM_XCD = 8;
 int gh_num_cu();
@@ -181,8 +182,5 @@ inline bool gh_tune_dynamic()
 #define GH_LAB_INT(name, dflt) (dflt)
 #define GH_KNOB_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return v_; }())
 #endif
-// (interim, files not yet split into release / lab dispatch: the old always-on knob)
-inline bool gh_tune_dynamic_old() { static const bool d = getenv("GH_TUNE_DYNAMIC") != nullptr; return d; }
-#define GH_TUNE_INT(name, dflt) ([] { static const int v_ = gh_env_int(name, dflt); return gh_tune_dynamic_old() ? gh_env_int(name, dflt) : v_; }())
 
 #endif  // __HIPCC__

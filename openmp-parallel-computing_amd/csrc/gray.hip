@@ -382,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_replicate_px(const uint8_t *__restric
 // large launch is absorbed by the stride loop (GH_GRAY_MAX_BLOCKS, tunable for experiments).
 inline unsigned grid_for(size_t items)
 {
-    const int knob = GH_TUNE_INT("GH_GRAY_MAX_BLOCKS", 0);       // tuning: cap the grid, the kernels grid-stride the rest
+    const int knob = GH_LAB_INT("GH_GRAY_MAX_BLOCKS", 0);       // tuning: cap the grid, the kernels grid-stride the rest
     const size_t cap = knob > 0 ? (size_t)knob : (size_t)1 << 20;
     size_t blocks = (items + BLOCK - 1) / BLOCK;
     if (blocks < 1) blocks = 1;

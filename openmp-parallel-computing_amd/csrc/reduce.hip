@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_mean_minmax(const uint8_t *__restrict
 inline unsigned reduce_grid(size_t items, int wg_per_cu)
 {
     size_t blocks = (items + BLOCK - 1) / BLOCK;
-    const int knob = GH_TUNE_INT("GH_REDUCE_WG_PER_CU", 0);
+    const int knob = GH_LAB_INT("GH_REDUCE_WG_PER_CU", 0);
     const size_t cap = (size_t)gh_num_cu() * (size_t)(knob > 0 ? knob : wg_per_cu);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;

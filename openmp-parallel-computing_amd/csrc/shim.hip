@@ -120,8 +120,11 @@ void gh_note_kernel(const char *name) { g_last_kernel = name; }
 
 int gh_num_cu()
 {
-    static const int forced = [] { const char *e = getenv("GH_NUM_CU_OVERRIDE"); return e ? atoi(e) : 0; }();
-    return forced > 0 ? forced : g_num_cu;
+#ifdef GH_ENABLE_PROBES
+    static const int forced = [] { const char *e = getenv("GH_NUM_CU_OVERRIDE"); return e ? atoi(e) : 0; }();      // launch-rule experiments
+    if (forced > 0) return forced;
+#endif
+    return g_num_cu;
 }
 int gh_num_xcd() { return g_num_xcd; }
 
@@ -257,24 +260,27 @@ int gh_pipeline_gray_sobel_dev(uint8_t *img, int width, int height, int channels
     const size_t npix = (size_t)width * height;
     if (npix == 0) return GH_OK;
     GH_REQUIRE(img && gray_ws && edge_ws, "null pointer");
+    // pass p (0-based) writes plane[(passes - 1 - p) & 1]: the planes alternate and the last pass lands in edge_ws
+    uint8_t *const plane[2] = {edge_ws, gray_ws};
+    GH_REQUIRE(gray_ws != edge_ws, "gray_ws and edge_ws must differ");
     for (int p = 0; p < passes; ++p) {
+        uint8_t *out = plane[(passes - 1 - p) & 1], *in = plane[(passes - p) & 1];
         int rc;
         if (p == 0 && channels >= 3) {
             // pass 1 in ONE kernel: RGB -> luma -> Sobel (the in-place luma write of the reference is dead: replicate overwrites
             // R,G,B; the luma plane is not needed afterwards -- later passes start from the edge plane)
-            if ((rc = gh_gray_sobel_fused_rows_dev(img, edge_ws, width, height, channels, mode, 1, 1, stream))) return rc;
-            continue;
-        } else if (p == 0) {
-            rc = gh_gray_rgb8_to_plane_dev(img, gray_ws, npix, channels, mode, stream);
+            rc = gh_gray_sobel_fused_rows_dev(img, out, width, height, channels, mode, 1, 1, stream);
+        } else if (p == 0) {                       // channels 1 / 2: the plane is channel 0, and every pass filters the plane as it is
+            if ((rc = gh_gray_rgb8_to_plane_dev(img, in, npix, channels, mode, stream))) return rc;
+            rc = gh_sobel_u8_dev(in, out, width, height, stream);
         } else if (channels >= 3) {
-            // the image now holds (e,e,e): its luma is lum(e,e,e), not e (13 grey levels move in IEEE mode)
-            rc = gh_gray_of_plane_dev(edge_ws, gray_ws, npix, mode, stream);
+            // the image now holds (e,e,e): its luma is lum(e,e,e), not e (13 grey levels move in IEEE mode) -- applied on load by the
+            // plane Sobel: one launch, 1 R + 1 W byte per pixel per pass (until round 4: a luma pass and a Sobel pass, 4 B/px)
+            rc = gh_sobel_of_gray_u8_dev(in, out, width, height, mode, stream);
         } else {
-            hipError_t e = hipMemcpyAsync(gray_ws, edge_ws, npix, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-            rc = e == hipSuccess ? GH_OK : gh_set_error(GH_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+            rc = gh_sobel_u8_dev(in, out, width, height, stream);
         }
         if (rc) return rc;
-        if ((rc = gh_sobel_u8_dev(gray_ws, edge_ws, width, height, stream))) return rc;
     }
     return gh_replicate_plane_dev(edge_ws, img, npix, channels, stream);
 }
@@ -296,8 +302,8 @@ int gh_gray_passes_host(unsigned char *data, int width, int height, int channels
     // Large frames: the pixels are independent, so the frame goes through in chunks -- an uploader thread copies chunk k+1
     // host -> device while this thread runs the kernel on chunk k and copies it back: PCIe is full duplex, the two directions
     // overlap (16384^2 RGB8: 29 ms -> see DESIGN.md section 5).  Small frames: one upload, one launch, one download.
-    const size_t chunk_px = (size_t)GH_TUNE_INT("GH_HOST_CHUNK_MPX", 16) << 20;          // multiple of 1024 px: whole wavefront groups
-    if (nbytes >= ((size_t)GH_TUNE_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && chunk_px > 0 && npix > 2 * chunk_px) {
+    const size_t chunk_px = (size_t)GH_LAB_INT("GH_HOST_CHUNK_MPX", 16) << 20;          // multiple of 1024 px: whole wavefront groups
+    if (nbytes >= ((size_t)GH_LAB_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && chunk_px > 0 && npix > 2 * chunk_px) {
         const int nchunk = (int)((npix + chunk_px - 1) / chunk_px);
         hipStream_t s_up = nullptr, s_dn = nullptr;
         if (int rc = host_pipeline_streams(&s_up, &s_dn)) return rc;
@@ -386,9 +392,9 @@ int gh_sobel_edge_host(const unsigned char *src, unsigned char *dst, int width, 
     // Large planes go through in row chunks like the gray driver above: an uploader thread copies chunk k+1 while this thread
     // filters the rows that chunk k completed -- output rows [kB - 1, (k+1)B - 1) need input rows up to (k+1)B - 1, i.e. chunks
     // 0..k -- and copies their interior back; both PCIe directions and the kernel overlap.
-    const size_t chunk_px = (size_t)GH_TUNE_INT("GH_HOST_CHUNK_MPX", 16) << 20;
+    const size_t chunk_px = (size_t)GH_LAB_INT("GH_HOST_CHUNK_MPX", 16) << 20;
     const int B = chunk_px ? (int)std::max<size_t>(64, chunk_px / (size_t)width) : 0;      // rows per chunk
-    if (npix >= ((size_t)GH_TUNE_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && B > 0 && height > 2 * B) {
+    if (npix >= ((size_t)GH_LAB_INT("GH_HOST_PIPELINE_MIN_MB", 64) << 20) && B > 0 && height > 2 * B) {
         const int nchunk = (height + B - 1) / B;
         hipStream_t s_up = nullptr, s_dn = nullptr;
         if (int rc = host_pipeline_streams(&s_up, &s_dn)) return rc;

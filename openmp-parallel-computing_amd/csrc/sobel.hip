@@ -10,8 +10,10 @@
 //                    16-byte aligned (first width & ~15 columns; k_sobel_px_cols takes the remaining columns)
 //   k_sobel_tiled  : the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h); GH_SOBEL_IMPL=tile
 //   k_sobel_px     : one pixel per lane, any geometry / alignment (small unaligned frames, widths < 16)
-#include "sobel_tile.h"
 #include "stream_core.h"
+#ifdef GH_ENABLE_PROBES
+#include "sobel_tile.h"
+#endif
 
 #include <cstdlib>
 #include <cstring>
@@ -19,13 +21,15 @@
 
 namespace {
 
+#ifdef GH_ENABLE_PROBES
 using namespace sobel_tile;
+#endif
 
 // ---- strip streaming ---------------------------------------------------------------------------------
 // R output rows per strip, C rows per load chunk; chunk ch+1 is in flight while chunk ch is computed.
 // CORE 0: packed-i16 row step (stream_core::row16); CORE 1: packed-f32 pair-layout row step (rowf2).  Both run with
 // MODE.fp_round = toward zero: this kernel has no rounding-sensitive float op (all sums are exact integers).
-template <int R, int C, int CORE>
+template <int R, int C, int CORE, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
                                                                     int rows, int groups_x, int zero_top, int zero_bot, int ws)
 {
@@ -44,7 +48,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
     if (xw + STRIP_PX > ws && ws >= STRIP_PX) xw = ws - STRIP_PX;   // last strip shifted left onto its neighbour: every strip is full
     const int x = xw + 16 * lane;
     const int y0 = gy_i * R;
-    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    static_assert(LUMA == 0 || CORE == 1, "luma on load: packed-f32 core only");
+    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
     const float half = half_reg();
     const f32x2 half2 = {half, half};
     const bool in_frame = x < ws;
@@ -84,15 +89,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
             if (CORE == 0) {
                 out = (j & 1) ? row16<1>(st16, q[j], ql, qr, half) : row16<0>(st16, q[j], ql, qr, half);
             } else {
-                // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
-                const uint32_t lo[2] = {q[j].x, q[j].y}, hi[2] = {q[j].z, q[j].w};
                 f32x2 G[10];
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
-                G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
-                G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
-                out = (j & 1) ? rowf2<1, 1>(stf, G, half2) : rowf2<0, 1>(stf, G, half2);
+                plane_row_pairs<LUMA>(q[j], ql, qr, G);
+                out = (j & 1) ? rowf2<1, LUMA == 0>(stf, G, half2) : rowf2<0, LUMA == 0>(stf, G, half2);
             }
             if (i >= 2) {
                 const int y = y0 + i - 2;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // early and the strip's first pixel sits at byte s = A mod 4 of the slot's lane grid: every ds_read stays naturally aligned.
 // UNAL = 1: s is 0 for every row (pitch and base multiples of 4): nothing else changes.  UNAL = 2: the lane's 16 pixels and
 // its two neighbours are re-aligned in registers, six v_alignbyte_b32 with the row's (wave-uniform) s.
-template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0, int REG = 0>
+template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0, int REG = 0, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
 {
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     // LAST row it requests, and the wait for the exchange sits right in front of that request
     const bool up = band_walks_up(plan, gy_i) || (hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows);
     if (hw.flag) gh_halo_started(hw);
-    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
     // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its byte 3),
@@ -259,15 +258,9 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             q.w = __builtin_amdgcn_alignbyte(qr, q.w, sh);
             qr >>= 8u * sh;
         }
-        // pair layout: G[m] = (p[m-1], p[m+7]); own pixels 0..7 live in q.x,q.y and 8..15 in q.z,q.w
-        const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
         f32x2 G[10];
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-            G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
-        G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
-        G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
-        uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
+        plane_row_pairs<LUMA>(q, ql, qr, G);
+        uint4 out = (j & 1) ? rowf2<1, LUMA == 0, PROBE == 1>(st, G, half2) : rowf2<0, LUMA == 0, PROBE == 1>(st, G, half2);
         if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
         if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
@@ -320,7 +313,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // early exits cost 70 more (allocated as AGPR spills in the tail, but they halve the residency of the whole kernel).
 // UNAL: rows of frames whose pitch or base is not a multiple of 16 start at the aligned address before the strip pair and land
 // dword-shifted (1), plus the byte re-alignment of both strips (2) -- exactly k_sobel_dma's scheme on a 2 KiB row.
-template <int D, int LB = 1, int REG = 0, int UNAL = 0>
+template <int D, int LB = 1, int REG = 0, int UNAL = 0, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
                                                                   int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
 {
@@ -347,7 +340,7 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     // sharded step, halo-flag form (gh_common.h; see k_fused_dma): first band upward, the wait in front of the halo row's request
     const bool up = hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows;
     if (hw.flag) gh_halo_started(hw);
-    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
+    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
     uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
@@ -428,14 +421,9 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
                 q.w = __builtin_amdgcn_alignbyte(qr, q.w, sh);
                 qr >>= 8u * sh;
             }
-            const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};
             f32x2 G[10];
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-                G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
-            G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
-            G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
-            uint4 out = (j & 1) ? rowf2<1, 1>(st, G, half2) : rowf2<0, 1>(st, G, half2);
+            plane_row_pairs<LUMA>(q, ql, qr, G);
+            uint4 out = (j & 1) ? rowf2<1, LUMA == 0>(st, G, half2) : rowf2<0, LUMA == 0>(st, G, half2);
             if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {       // y < rows by construction of nrows
                 if (SUB == 0) out.x &= first_col_mask;               // the frame's first / last column is border: written as 0
                 if (SUB == 1) out.w &= last_col_mask;
@@ -480,6 +468,8 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
         if (chunk(std::integral_constant<int, 0>{}, ch)) return;
 }
 
+#ifdef GH_ENABLE_PROBES
+// ======== measurement lab: variants that lost their A/B (kept selectable in probe builds, `make probes`) and access-pattern probes ========
 // ---- four strips per wave: 4 KiB of every row, packed-i16 state ------------------------------------------------------------------------
 // The no-arithmetic skeletons (DESIGN.md / NOTES.md) say a wave that owns 4 KiB of every row reads closer to a linear stream than one that
 // owns 1 or 2 KiB; the f32 pair state of k_sobel_dma2 (64 VGPRs per strip) stops at two strips.  The packed-i16 state (State16, 32 VGPRs
@@ -593,7 +583,6 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma4(const uint8_t
     chunk(std::integral_constant<int, 4>{}, nch - 1);
 }
 
-#ifdef GH_ENABLE_PROBES
 // ---- access-pattern probe: wider strips -- a wave owns PIECES KiB of every row (PIECES LDS-DMA pieces + the halo dword per row step) ----
 // The fused kernel (3 KiB of RGB per wave and row) sits closer to its linear-copy ceiling than the plane Sobel (1 KiB): is it the
 // size of the contiguous piece a wave reads per row?  Same ring, waits and stores as k_sobel_dma's no-arithmetic skeleton
@@ -797,8 +786,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_march_probe(const uint8_
         }
     }
 }
-#endif
 
+// ---- the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h): the first version measured, 0.134 ms against 0.095 -----------
 using stream_core::row_readable;
 
 __global__ __launch_bounds__(BLOCK) void k_sobel_tiled(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
@@ -832,43 +821,31 @@ __global__ __launch_bounds__(BLOCK) void k_sobel_tiled(const uint8_t *__restrict
     compute_tile(tile, dst, w, rows, x0, y0, zero_top, zero_bot);
 }
 
-// One pixel per lane; rows above/below the band are read only when they exist.
-__global__ __launch_bounds__(BLOCK) void k_sobel_px(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
-                                                    int zero_top, int zero_bot)
-{
-    const size_t n = (size_t)w * rows;
-    const size_t stride = (size_t)gridDim.x * BLOCK;
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
-        uint32_t out = 0;
-        const bool border = x == 0 || x == w - 1 || (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
-        if (!border) {
-            const uint8_t *m = src + (ptrdiff_t)y * w + x;
-            const uint8_t *u = m - w, *d = m + w;
-            const int gx = -(int)u[-1] - 2 * (int)m[-1] - (int)d[-1] + (int)u[1] + 2 * (int)m[1] + (int)d[1];
-            const int gy = (int)u[-1] + 2 * (int)u[0] + (int)u[1] - (int)d[-1] - 2 * (int)d[0] - (int)d[1];
-            out = gh_sobel_mag(gx * gx + gy * gy);
-        }
-        dst[i] = (uint8_t)out;
-    }
-}
+#endif   // GH_ENABLE_PROBES
 
-// The last w % 16 columns of a frame whose width is not a multiple of 16 (the strip kernel covers the rest).
-__global__ __launch_bounds__(BLOCK) void k_sobel_px_cols(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int x0,
-                                                         int zero_top, int zero_bot)
+// One pixel per lane; rows above/below the band are read only when they exist.  x0 > 0: only the columns [x0, w) (the last w % 16 columns of a
+// frame whose width is not a multiple of 16: the strip kernel covers the rest).  LUMA = 1 / 2: every byte read goes through lum(e, e, e)
+// first (stream_core::plane_row_pairs explains why), here with the scalar gh_luma of gh_common.h.
+template <int LUMA>
+__global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_px(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int x0,
+                                                                int zero_top, int zero_bot)
 {
     const int nc = w - x0;
     const size_t n = (size_t)nc * rows;
-    const size_t stride = (size_t)gridDim.x * BLOCK;
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const size_t stride = (size_t)gridDim.x * stream_core::BLOCK;
+    auto px = [](const uint8_t *p) -> int {
+        const uint32_t v = *p;
+        return LUMA ? (int)gh_luma<LUMA ? LUMA - 1 : 0>(v, v, v) : (int)v;
+    };
+    for (size_t i = (size_t)blockIdx.x * stream_core::BLOCK + threadIdx.x; i < n; i += stride) {
         const int y = (int)(i / nc), x = x0 + (int)(i - (size_t)y * nc);
         uint32_t out = 0;
         const bool border = x == 0 || x == w - 1 || (y == 0 && zero_top) || (y == rows - 1 && zero_bot);
         if (!border) {
             const uint8_t *m = src + (ptrdiff_t)y * w + x;
             const uint8_t *u = m - w, *d = m + w;
-            const int gx = -(int)u[-1] - 2 * (int)m[-1] - (int)d[-1] + (int)u[1] + 2 * (int)m[1] + (int)d[1];
-            const int gy = (int)u[-1] + 2 * (int)u[0] + (int)u[1] - (int)d[-1] - 2 * (int)d[0] - (int)d[1];
+            const int gx = -px(u - 1) - 2 * px(m - 1) - px(d - 1) + px(u + 1) + 2 * px(m + 1) + px(d + 1);
+            const int gy = px(u - 1) + 2 * px(u) + px(u + 1) - px(d - 1) - 2 * px(d) - px(d + 1);
             out = gh_sobel_mag(gx * gx + gy * gy);
         }
         dst[(size_t)y * w + x] = (uint8_t)out;
@@ -911,264 +888,329 @@ extern "C" {
 int gh_sobel_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border,
                          gh_stream_t stream)
 {
-    return gh_sobel_rows_halo_wait(src, dst, width, rows, top_is_border, bottom_is_border, stream, nullptr);
+    return gh_sobel_rows_halo_wait(src, dst, width, rows, top_is_border, bottom_is_border, stream, nullptr, 0);
+}
+
+// Pass k >= 2 of the reference's gray + Sobel driver loop in ONE kernel (monolithic/src/main_with_sobel.c:51-62 applied to pass k - 1's
+// replicated edge image): src holds the previous pass's edge plane e, every byte goes through lum(e, e, e) on its way into the Sobel
+// window.  1 R + 1 W byte per pixel instead of the 2 + 2 of gh_gray_of_plane_dev followed by gh_sobel_u8_rows_dev.
+int gh_sobel_of_gray_u8_rows_dev(const uint8_t *src, uint8_t *dst, int width, int rows, int mode, int top_is_border, int bottom_is_border,
+                                 gh_stream_t stream)
+{
+    GH_REQUIRE(mode == GH_MODE_IEEE || mode == GH_MODE_FMA, "bad mode");
+    return gh_sobel_rows_halo_wait(src, dst, width, rows, top_is_border, bottom_is_border, stream, nullptr, 1 + mode);
+}
+
+int gh_sobel_of_gray_u8_dev(const uint8_t *src, uint8_t *dst, int width, int height, int mode, gh_stream_t stream)
+{
+    return gh_sobel_of_gray_u8_rows_dev(src, dst, width, height, mode, 1, 1, stream);
 }
 
 }  // extern "C"
 
+// The launcher of every plane-Sobel entry point.
 // hw != nullptr: the halo-flag form of the sharded step (gh_common.h) -- only the LDS-DMA ring kernels carry the wait; a frame that would
 // run another form (or the two-launch split of k_sobel_dma2) is refused with GH_NO_FLAG_FORM before anything is launched.
+// luma: 0 = the plane as it is, 1 / 2 = lum(e, e, e) applied on load in IEEE / FMA arithmetic (stream_core::plane_row_pairs).
+// GH_LAB_INT knobs are compile-time constants in the release library (gh_common.h); what they select beyond their defaults exists in
+// probe builds only.
 int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int rows, int top_is_border, int bottom_is_border, gh_stream_t stream,
-                            const GhHaloWait *hw)
+                            const GhHaloWait *hw, int luma)
 {
     GH_REQUIRE(width >= 0 && rows >= 0, "negative size");
+    GH_REQUIRE(luma >= 0 && luma <= 2, "luma must be 0 (none), 1 (IEEE) or 2 (FMA)");
     if (width == 0 || rows == 0) return GH_OK;
     GH_REQUIRE(src && dst, "null pointer");
     GH_REQUIRE(src != dst, "src and dst must differ");
     if (int rc = gh_ensure_init()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
-    static const bool use_tile = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
     const bool aligned = width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst);
+    bool use_tile = false;
+    int core = 1;
+#ifdef GH_ENABLE_PROBES
+    static const bool tile_env = [] { const char *e = getenv("GH_SOBEL_IMPL"); return e && strcmp(e, "tile") == 0; }();
+    static const int core_env = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
+    use_tile = tile_env && !luma;       // (the lab's other cores carry no luma-on-load form)
+    core = luma ? 1 : core_env;
+#endif
+    const unsigned b = stream_core::BLOCK;
+    const char *const sfx = luma ? " luma-on-load" : "";
+    static thread_local char kname[96];
+    auto note = [&](const char *name) { snprintf(kname, sizeof kname, "%s%s", name, sfx); gh_note_kernel(kname); };
+    auto launch_px = [&](int x0) {
+        size_t blocks = ((size_t)(width - x0) * rows + b - 1) / b;
+        const size_t cap = x0 ? 4096 : (1u << 20);
+        if (blocks > cap) blocks = cap;
+        if (luma == 1) k_sobel_px<1><<<(unsigned)blocks, b, 0, s>>>(src, dst, width, rows, x0, zt, zb);
+        else if (luma == 2) k_sobel_px<2><<<(unsigned)blocks, b, 0, s>>>(src, dst, width, rows, x0, zt, zb);
+        else k_sobel_px<0><<<(unsigned)blocks, b, 0, s>>>(src, dst, width, rows, x0, zt, zb);
+    };
     // Widths that are not a multiple of 16 (or unaligned planes): the register-staged strip kernel runs on the first
     // ws = width & ~15 columns with unaligned vector accesses (rows start at arbitrary bytes), the per-pixel kernel takes
     // the last width % 16 columns.  (All per-pixel: 0.69 ms on 16370 x 16384; this way: 0.125 ms.)
     const int ws = width & ~15;
     // (small unaligned frames stay on the single per-pixel launch: 1921 x 1081 takes 7 us that way, 11 us as strips + tail)
-    static const int core = [] { const char *e = getenv("GH_SOBEL_CORE"); return (e && strcmp(e, "i16") == 0) ? 0 : 1; }();
-    const int dma = GH_TUNE_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (0 = register-staged kernel)
+    const int dma = GH_LAB_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (probe builds: 0 = register-staged kernel, other depths, probes)
     // The LDS-DMA kernel takes ANY width >= 1024 and any base alignment: a DMA piece is 64 lanes x 16 B from consecutive global
     // addresses that need no alignment (only the LDS side is lane-linear), every strip is full (the last one is shifted left
     // to end at the frame edge), so a row pitch that is not a multiple of 16 changes nothing but the address arithmetic --
-    // no per-pixel column tail.  GH_SOBEL_DMA_UNALIGNED=0 sends such frames back to the register-staged strips + tail.
-    const bool use_dma = !use_tile && dma && core == 1 && width >= stream_core::STRIP_PX && (aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 1));
+    // no per-pixel column tail.
+    const int dma_unal = GH_LAB_INT("GH_SOBEL_DMA_UNALIGNED", 2);      // 2 aligned-down pieces (UNAL), 1 pieces from the strip's own address, 0 strips + tail
+    const bool use_dma = !use_tile && dma && core == 1 && width >= stream_core::STRIP_PX && (aligned || dma_unal);
     if (hw && (!use_dma || dma != 3)) return GH_NO_FLAG_FORM;      // (dma != 3: the probe forms)
     const GhHaloWait hwv = hw ? *hw : GhHaloWait{};
     const bool strips = !use_tile && ws >= 16 &&
-                        (aligned || use_dma || (GH_TUNE_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_TUNE_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
-    if (strips) {
-        const int r_env = GH_TUNE_INT("GH_SOBEL_R", 0);   // tuning knob
-        const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
-        const int groups_x = ((use_dma ? width : ws) + span - 1) / span;
-        // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 64)
-        // but a shard must still give every CU a few workgroups.  Power-of-two heights only: band starts aligned to
-        // 2^k rows measured 10-15 % faster than 30 / 34 / 48 / 60-row bands in the no-compute strip-copy probe.
-        int R = r_env;
-        // the LDS-DMA kernel takes any band height (tuning knob); the register-staged one is instantiated for 16 / 32 / 64
-        if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64) {
-            R = stream_core::sobel_band_rows(groups_x, rows, width, gh_num_cu(), use_dma, GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) != 0, GH_TUNE_INT("GH_SOBEL_REG", 1) != 0);
-        }
-        const long long nb = (long long)groups_x * ((rows + R - 1) / R);
-        GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
-        const unsigned g = (unsigned)nb, b = stream_core::BLOCK;
-        if (use_dma) {
-            // dispatch order 8 (pairs-per-XCD: XCD x owns the band pairs p = x mod 8): +1-2 % on 16384^2 in four interleaved
-            // A/B runs, +14 % on 32768 x 8192, neutral on shards (tools/ab_fused.py --op sobel)
-            stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-            plan.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), plan.bands, groups_x, gh_num_xcd());
-            const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);      // (shadows the register-staged kernel's grid)
-            
-            const size_t pad = (size_t)GH_TUNE_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
-            // Output store policy: nontemporal.  sc1 / plain stores LOOK 8-12 % faster when the same 268 MB output plane is
-            // rewritten launch after launch (74.7 % vs 66.7 %): the 256 MB Infinity Cache absorbs the writes and they never
-            // reach HBM.  With the output rotating over six planes it is the other way round (sc1 62.6 %, plain 60.7 %,
-            // nt 66.8 %; tools/ab_fused.py --out-ring 6), and nt performs the same in both settings.
-            const int sp = GH_TUNE_INT("GH_SOBEL_ST", 2);        // 2 nt (default), 0 plain, 1 sc1
-            // frames with unaligned rows: GH_SOBEL_DMA_UNALIGNED = 2 (default) aligned-down pieces (k_sobel_dma, UNAL), 1 = pieces
-            // from the strip's own unaligned address, 0 = register-staged strips + column tail (further down)
-            // Two strips per wave (k_sobel_dma2, regular-band form): frames whose rows split into whole bands of 64 or 16 rows
-            // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/sweep.py r2_ai,
-            // sweep.py r2_aj): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
-            // 0.0521 / 0.0262 vs 0.0309 / 0.0166 vs 0.0185, 8192^2 0.0270 vs 0.0288, 7680 x 4352 0.0230 vs 0.0246; narrow or small
-            // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
-            // 64-row bands when they still give every CU a workgroup, else 16.  GH_SOBEL_NS = 1: never, 2: whenever the geometry allows.
-            const int ns_knob = GH_TUNE_INT("GH_SOBEL_NS", 0);
-            // Four strips per wave (k_sobel_dma4): on request only (GH_SOBEL_NS=4) -- measured against k_sobel_dma2 in NOTES.md.  Aligned frames
-            // of 4096 columns and more whose rows hold a whole band; GH_SOBEL_NS4_D ring depth (3, 2 or 6), GH_SOBEL_NS4_CORE 1 packed-f32
-            // magnitude / 0 the plain packed-i16 core, GH_SOBEL_R band height (64; R + 2 rows in whole chunks of the unroll).
-            if (ns_knob == 4 && aligned && dma == 3 && sp == 2 && width >= 4 * stream_core::STRIP_PX) {
-                const int d4 = GH_TUNE_INT("GH_SOBEL_NS4_D", 3), core4 = GH_TUNE_INT("GH_SOBEL_NS4_CORE", 1);
-                const int R4 = r_env > 0 ? r_env : 64, chk4 = d4 == 3 ? 6 : d4;
-                const int quads = (width + 4 * stream_core::STRIP_PX - 1) / (4 * stream_core::STRIP_PX), gx4 = (quads + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
-                if ((d4 == 2 || d4 == 3 || d4 == 6) && (R4 + 2) % chk4 == 0 && (R4 + 2) / chk4 >= 3 && rows >= R4) {
-                    if (hw && hw->pad) return GH_OK;
-                    stream_core::BandPlan p4 = stream_core::make_band_plan(rows, R4, -1, 0, -1, 0);
-                    p4.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p4.bands, gx4, gh_num_xcd());
-                    const unsigned g4 = (unsigned)stream_core::plan_grid(p4, gx4);
-                    gh_note_kernel(core4 ? "k_sobel_dma4 packed-f32 magnitude" : "k_sobel_dma4");
-                    if (d4 == 2) { if (core4) k_sobel_dma4<2, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<2, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
-                    else if (d4 == 6) { if (core4) k_sobel_dma4<6, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<6, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
-                    else { if (core4) k_sobel_dma4<3, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<3, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
-                    GH_LAUNCH_CHECK();
-                    return GH_OK;
-                }
-            }
-            const int unal2 = aligned ? 0 : (GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
-            if (unal2 >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
-                const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
-                // 64-row bands from one workgroup per CU up -- below two per CU only when they spread evenly over the CUs (16384 x 12288: 384
-                // workgroups, 0.0863 ms against 0.0749 with 16-row bands)
-                const long long nb64_2 = (long long)gx2 * (rows / 64);
-                const bool even64 = nb64_2 >= 2 * gh_num_cu() || (nb64_2 >= gh_num_cu() && stream_core::wg_balance(nb64_2, gh_num_cu()) >= 0.97);
-                int R2 = r_env > 0 ? r_env : (even64 ? 64 : 16);
-                if (r_env <= 0 && R2 == 64 && GH_TUNE_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R2 = 16;
-                const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
-                // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
-                //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips)
-                const bool wanted = ns_knob == 2 || (unal2 == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * gh_num_cu());
-                // rows that do not split into whole bands: the kernel shifts the last band up -- unless the whole bands fill the 512 resident
-                // slots exactly; then the whole bands here and the ragged rest (fewer than R2 rows, real halo row above) in a second launch
-                // (the second launch costs ~10 us: only where the first one is long -- 16384 x 16390 0.1076 ms this way, 0.1146 on the one-strip kernel;
-                //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
-                const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, gh_num_cu());
-                if (overflow2 && (long long)width * rows >= (long long)GH_TUNE_INT("GH_SOBEL_SPLIT_MIN_PX", 1 << 28)) {
-                    if (hw) return GH_NO_FLAG_FORM;
-                    const int main_rows = rows - rows % R2;
-                    if (int rc = gh_sobel_u8_rows_dev(src, dst, width, main_rows, top_is_border, 0, stream)) return rc;
-                    return gh_sobel_u8_rows_dev(src + (size_t)main_rows * width, dst + (size_t)main_rows * width, width, rows - main_rows, 0, bottom_is_border, stream);
-                }
-                const bool regular = band_ok && rows >= R2 && !overflow2;                          // (a ragged last band is shifted up inside the kernel)
-                // (frames with unaligned rows only on request: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
-                //  one strip per wave -- the gain belongs to row pitches that keep the row streams in step; 16368 wide: 0.1079 vs 0.1086)
-                if (regular && wanted) {
-                    if (hw && hw->pad) return GH_OK;      // probe: k_sobel_dma2 will run
-                    stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
-                    p2.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8) % 1000, p2.bands, gx2, gh_num_xcd());
-                    const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
+                        (aligned || use_dma || (GH_LAB_INT("GH_SOBEL_UNALIGNED", 1) && (long long)width * rows >= GH_LAB_INT("GH_SOBEL_UNALIGNED_MIN_PX", 1 << 21)));
+    if (!strips) {
 #ifdef GH_ENABLE_PROBES
-                    const int nsd = GH_TUNE_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: DESIGN.md)
-                    if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                    else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                    else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                    else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);     // regular-band form, other depths
-                    else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                    else
-#endif
-                    {
-                        gh_note_kernel(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
-                        if (unal2 == 0) k_sobel_dma2<3, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                        else if (unal2 == 1) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                        else k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                    }
-                    GH_LAUNCH_CHECK();
-                    return GH_OK;
-                }
-            }
-            if (hw && hw->pad) return GH_OK;              // probe: k_sobel_dma will run
-            const int unal = aligned || GH_TUNE_INT("GH_SOBEL_DMA_UNALIGNED", 2) < 2 ? 0 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2);
-            // Regular-band (branch-free) form of the one-strip kernel, 128-134 VGPRs: every band has R + 2 input rows in whole chunks of 6.
-            // With 16-row bands -- the mid-size and small frames, where a wave's row step is latency-bound and the generic form's scalar
-            // branches count -- it is 7-20 % faster (7680 x 4352 0.0198 vs 0.0249 ms, 4096^2 0.0115 vs 0.0129, 16384 x 1024 0.0117 vs 0.0134,
-            // 3840 x 2160 0.0108 vs 0.0119, 1920 x 1088 0.0100 vs 0.0107); with 64-row bands on large frames it only lets a third workgroup
-            // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.  GH_SOBEL_REG=0: never.
-            const bool reg1 = GH_TUNE_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows >= R && plan.n[1] == 0 && plan.order < 1000 &&
-                              !stream_core::shifted_band_overflows(groups_x, rows, R, 3, gh_num_cu());
-            gh_note_kernel(reg1 ? (unal ? "k_sobel_dma regular R=16 unaligned" : "k_sobel_dma regular R=16") : (unal ? "k_sobel_dma unaligned" : "k_sobel_dma"));
-            if (reg1) {
-                if (unal == 0) k_sobel_dma<3, 0, 2, 1, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-                else if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-                else k_sobel_dma<3, 0, 2, 1, 2, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            }
-            else if (unal && sp == 0) {
-                if (unal == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-                else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            } else if (unal) {
-                if (unal == 1) k_sobel_dma<3, 0, 2, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-                else k_sobel_dma<3, 0, 2, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            }
-            else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-#ifdef GH_ENABLE_PROBES
-            else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW
-                const int rw = dma - 100, skew = GH_TUNE_INT("GH_SOBEL_SKEW", 3);
-                const unsigned gm = (unsigned)((rows + 4 * rw - 1) / (4 * rw));
-                if (rw == 4) k_march_probe<4><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
-                else if (rw == 6) k_march_probe<6><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
-                else if (rw == 8) k_march_probe<8><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
-                else if (rw == 14) k_march_probe<14><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
-                else k_march_probe<2><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
-            }
-            else if (dma >= 200 && dma < 1800 && (dma % 100 >= 2 && dma % 100 <= 4) && width % (dma >= 1700 ? 4096 : 1024 * (dma / 100) * (dma >= 1600 ? 1 : (dma >= 800 ? 2 : 4))) == 0 && rows % R == 0) {
-                // wide-strip probe: dma = 100 * KiB per wave and row + ring depth (8 and 16 KiB: two / one wave per workgroup)
-                const int pieces = dma >= 1700 ? 1 : dma / 100, wpb = pieces >= 16 ? 1 : (pieces >= 8 ? 2 : 4), gxw = width / (1024 * pieces * wpb);
-                stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 8), pw.bands, gxw, gh_num_xcd());
-                const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
-                if (dma == 203) k_wide_strip_probe<2, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 202) k_wide_strip_probe<2, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 403) k_wide_strip_probe<4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 402) k_wide_strip_probe<4, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 803) k_wide_strip_probe<8, 3, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 802) k_wide_strip_probe<8, 2, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 1703) k_loader_probe<3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);      // 17xx: the loader-wave probe (4 KiB per workgroup and row)
-                else if (dma == 1704) k_loader_probe<4><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 1603) k_wide_strip_probe<16, 3, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 1602) k_wide_strip_probe<16, 2, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else GH_REQUIRE(false, "wide-strip probe: unknown size / depth");
-            }
-            else if (dma >= 30000 && dma < 40000 && width % 12288 == 0 && rows % R == 0) {
-                // 3:1 wide-strip probe on a plane of 3 x 16384 bytes per row: dma = 30000 + 100 * KiB read per wave and row + ring depth
-                const int pieces = (dma - 30000) / 100, depth = dma % 100, wpb = pieces >= 12 ? (depth == 3 ? 1 : 2) : (pieces >= 6 ? (depth == 3 ? 2 : 4) : 4);
-                const int gxw = width / (1024 * pieces * wpb);
-                stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
-                pw.order = stream_core::sanitize_order(GH_TUNE_INT("GH_SOBEL_ORDER", 6), pw.bands, gxw, gh_num_xcd());
-                const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
-                if (dma == 30302) k_wide_strip_probe<3, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 30303) k_wide_strip_probe<3, 3, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 30602) k_wide_strip_probe<6, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 30603) k_wide_strip_probe<6, 3, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 31202) k_wide_strip_probe<12, 2, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else if (dma == 31203) k_wide_strip_probe<12, 3, 1, 3><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
-                else GH_REQUIRE(false, "3:1 wide-strip probe: unknown size / depth");
-            }
-            else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no sqrt (wrong results)
-            else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no arithmetic (wrong results)
-            else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // probe: row-synchronous workgroup
-            else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // the same without arithmetic
-            else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);  // probe: default-policy DMA loads
-            else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-#endif
-            else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            else if (dma == 3) k_sobel_dma<3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-            else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        if (aligned && !luma) {           // GH_SOBEL_IMPL=tile
+            const int tiles_x = (width + sobel_tile::TW - 1) / sobel_tile::TW, tiles_y = (rows + sobel_tile::TH - 1) / sobel_tile::TH;
+            const long long nt = (long long)tiles_x * tiles_y;
+            GH_REQUIRE(nt < (1ll << 31), "frame too large for one launch");
+            gh_note_kernel("k_sobel_tiled");
+            k_sobel_tiled<<<(unsigned)nt, sobel_tile::BLOCK, 0, s>>>(src, dst, width, rows, tiles_x, zt, zb);
             GH_LAUNCH_CHECK();
             return GH_OK;
         }
-        gh_note_kernel(ws < width ? "k_sobel_stream + k_sobel_px_cols" : "k_sobel_stream");
-#define GH_SOBEL_LAUNCH(R_, C_)                                                                                      \
-        do {                                                                                                         \
-            if (core == 0) k_sobel_stream<R_, C_, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);       \
-            else k_sobel_stream<R_, C_, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                 \
+#endif
+        note("k_sobel_px");
+        launch_px(0);
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+    const int r_env = GH_LAB_INT("GH_SOBEL_R", 0);
+    const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
+    const int groups_x = ((use_dma ? width : ws) + span - 1) / span;
+    // strip height: taller strips re-read fewer halo rows from HBM (2 per strip: 12.5 % at R = 16, 3 % at R = 64)
+    // but a shard must still give every CU a few workgroups.  Power-of-two heights only: band starts aligned to
+    // 2^k rows measured 10-15 % faster than 30 / 34 / 48 / 60-row bands in the no-compute strip-copy probe.
+    int R = r_env;
+    // (the LDS-DMA kernel takes any band height -- a lab knob; the register-staged one is instantiated for 16 / 32 / 64)
+    if (!(use_dma && R > 0) && R != 16 && R != 32 && R != 64)
+        R = stream_core::sobel_band_rows(groups_x, rows, width, gh_num_cu(), use_dma, GH_LAB_INT("GH_BAND_ALIAS_RULE", 1) != 0, GH_LAB_INT("GH_SOBEL_REG", 1) != 0);
+    const long long nb = (long long)groups_x * ((rows + R - 1) / R);
+    GH_REQUIRE(nb < (1ll << 31), "frame too large for one launch");
+    if (!use_dma) {
+        // register-staged strips: frames narrower than 1024 columns
+        const unsigned g = (unsigned)nb;
+        note(ws < width ? "k_sobel_stream + k_sobel_px" : "k_sobel_stream");
+#define GH_SOBEL_STREAM(R_)                                                                                                        \
+        do {                                                                                                                         \
+            if (luma == 1) k_sobel_stream<R_, 2, 1, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                  \
+            else if (luma == 2) k_sobel_stream<R_, 2, 1, 2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);             \
+            else if (GH_LAB && core == 0) k_sobel_stream<R_, 2, GH_LAB ? 0 : 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);   \
+            else k_sobel_stream<R_, 2, 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                            \
         } while (0)
         switch (R) {
-        case 64: GH_SOBEL_LAUNCH(64, 2); break;
-        case 32: GH_SOBEL_LAUNCH(32, 2); break;
-        default: GH_SOBEL_LAUNCH(16, 2); break;
+        case 64: GH_SOBEL_STREAM(64); break;
+        case 32: GH_SOBEL_STREAM(32); break;
+        default: GH_SOBEL_STREAM(16); break;
         }
-#undef GH_SOBEL_LAUNCH
+#undef GH_SOBEL_STREAM
+        GH_LAUNCH_CHECK();
         if (ws < width) {
+            launch_px(ws);
             GH_LAUNCH_CHECK();
-            size_t blocks = ((size_t)(width - ws) * rows + BLOCK - 1) / BLOCK;
-            if (blocks > 4096) blocks = 4096;
-            k_sobel_px_cols<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, rows, ws, zt, zb);
         }
-    } else if (aligned) {
-        const int tiles_x = (width + TW - 1) / TW;
-        const int tiles_y = (rows + TH - 1) / TH;
-        const long long nt = (long long)tiles_x * tiles_y;
-        GH_REQUIRE(nt < (1ll << 31), "frame too large for one launch");
-        gh_note_kernel("k_sobel_tiled");
-        k_sobel_tiled<<<(unsigned)nt, BLOCK, 0, s>>>(src, dst, width, rows, tiles_x, zt, zb);
-    } else {
-        size_t blocks = ((size_t)width * rows + BLOCK - 1) / BLOCK;
-        if (blocks > (1u << 20)) blocks = 1u << 20;
-        gh_note_kernel("k_sobel_px");
-        k_sobel_px<<<(unsigned)blocks, BLOCK, 0, s>>>(src, dst, width, rows, zt, zb);
+        return GH_OK;
     }
+
+    // ---- LDS-DMA ring kernels ---------------------------------------------------------------------------------------------------------
+    // dispatch order 8 (pairs-per-XCD: XCD x owns the band pairs p = x mod 8): +1-2 % on 16384^2 in four interleaved
+    // A/B runs, +14 % on 32768 x 8192, neutral on shards (tools/ab_fused.py --op sobel)
+    const int order_knob = GH_LAB_INT("GH_SOBEL_ORDER", 8);
+    stream_core::BandPlan plan = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+    plan.order = stream_core::sanitize_order(order_knob, plan.bands, groups_x, gh_num_xcd());
+    const unsigned g = (unsigned)stream_core::plan_grid(plan, groups_x);
+    const size_t pad = (size_t)GH_LAB_INT("GH_SOBEL_PAD_KB", 0) * 1024;   // occupancy probe: unused dynamic LDS
+    // Output store policy: nontemporal.  sc1 / plain stores LOOK 8-12 % faster when the same 268 MB output plane is
+    // rewritten launch after launch (74.7 % vs 66.7 %): the 256 MB Infinity Cache absorbs the writes and they never
+    // reach HBM.  With the output rotating over six planes it is the other way round (sc1 62.6 %, plain 60.7 %,
+    // nt 66.8 %; tools/ab_fused.py --out-ring 6), and nt performs the same in both settings.
+    const int sp = GH_LAB_INT("GH_SOBEL_ST", 2);        // 2 nt; probe builds: 0 plain, 1 sc1
+    // Two strips per wave (k_sobel_dma2, regular-band form): frames whose rows split into whole bands of 64 or 16 rows
+    // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/sweep.py r2_ai,
+    // sweep.py r2_aj): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
+    // 0.0521 / 0.0262 vs 0.0309 / 0.0166 vs 0.0185, 8192^2 0.0270 vs 0.0288, 7680 x 4352 0.0230 vs 0.0246; narrow or small
+    // frames lose (4096 x 16384: two of a workgroup's four waves idle; 4096^2, 16384 x 1024: too few waves) and stay where they were.
+    // 64-row bands when they still give every CU a workgroup, else 16.  (GH_SOBEL_NS, probe builds: 1 never, 2 whenever the geometry
+    // allows, 4 the four-strip kernel that lost its A/B: 59.7-65.0 % against 68.8 %, NOTES.md R3.4.)
+    const int ns_knob = GH_LAB_INT("GH_SOBEL_NS", 0);
+#ifdef GH_ENABLE_PROBES
+    if (ns_knob == 4 && !luma && aligned && dma == 3 && sp == 2 && width >= 4 * stream_core::STRIP_PX) {
+        const int d4 = GH_LAB_INT("GH_SOBEL_NS4_D", 3), core4 = GH_LAB_INT("GH_SOBEL_NS4_CORE", 1);
+        const int R4 = r_env > 0 ? r_env : 64, chk4 = d4 == 3 ? 6 : d4;
+        const int quads = (width + 4 * stream_core::STRIP_PX - 1) / (4 * stream_core::STRIP_PX), gx4 = (quads + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
+        if ((d4 == 2 || d4 == 3 || d4 == 6) && (R4 + 2) % chk4 == 0 && (R4 + 2) / chk4 >= 3 && rows >= R4) {
+            if (hw && hw->pad) return GH_OK;
+            stream_core::BandPlan p4 = stream_core::make_band_plan(rows, R4, -1, 0, -1, 0);
+            p4.order = stream_core::sanitize_order(order_knob % 1000, p4.bands, gx4, gh_num_xcd());
+            const unsigned g4 = (unsigned)stream_core::plan_grid(p4, gx4);
+            gh_note_kernel(core4 ? "k_sobel_dma4 packed-f32 magnitude" : "k_sobel_dma4");
+            if (d4 == 2) { if (core4) k_sobel_dma4<2, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<2, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+            else if (d4 == 6) { if (core4) k_sobel_dma4<6, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<6, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+            else { if (core4) k_sobel_dma4<3, 1><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); else k_sobel_dma4<3, 0><<<g4, b, pad, s>>>(src, dst, width, rows, gx4, p4, zt, zb, hwv); }
+            GH_LAUNCH_CHECK();
+            return GH_OK;
+        }
+    }
+#endif
+    // 0 aligned rows, 1 rows that start on a dword (pieces land dword-shifted), 2 any byte (+ v_alignbyte); -1: no aligned-down form asked for
+    const int unal = aligned ? 0 : (dma_unal < 2 ? -1 : ((width % 4 == 0 && ((uintptr_t)src & 3) == 0) ? 1 : 2));
+    if (unal >= 0 && dma == 3 && sp == 2 && ns_knob != 1 && width >= 2 * stream_core::STRIP_PX) {
+        const int pairs = (width + 2 * stream_core::STRIP_PX - 1) / (2 * stream_core::STRIP_PX), gx2 = (pairs + stream_core::WAVES_PER_BLOCK - 1) / stream_core::WAVES_PER_BLOCK;
+        // 64-row bands from one workgroup per CU up -- below two per CU only when they spread evenly over the CUs (16384 x 12288: 384
+        // workgroups, 0.0863 ms against 0.0749 with 16-row bands)
+        const long long nb64_2 = (long long)gx2 * (rows / 64);
+        const bool even64 = nb64_2 >= 2 * gh_num_cu() || (nb64_2 >= gh_num_cu() && stream_core::wg_balance(nb64_2, gh_num_cu()) >= 0.97);
+        int R2 = r_env > 0 ? r_env : (even64 ? 64 : 16);
+        if (r_env <= 0 && R2 == 64 && GH_LAB_INT("GH_BAND_ALIAS_RULE", 1) && stream_core::prefer_short_bands(width, 64, 16)) R2 = 16;
+        const bool band_ok = R2 >= 16 && (R2 + 2) % 6 == 0;                             // R2 + 2 input rows = whole chunks of 6
+        // (widths that are multiples of 8192 only: that is where the row streams stay in step and the wider pieces pay -- 12288 x 8192 and
+        //  7680 x 4352 run 0.0380 / 0.0198 ms on the one-strip regular-band form below and 0.0433 / 0.0230 with two strips; frames with
+        //  unaligned rows only on request in probe builds: 16370 / 16380 x 16384 measure 0.1116 / 0.1108 ms this way and 0.1099 / 0.1084 with
+        //  one strip per wave)
+        const bool wanted = (GH_LAB && ns_knob == 2) || (unal == 0 && width % 8192 == 0 && (long long)pairs * (rows / R2) >= 4 * gh_num_cu());
+        // rows that do not split into whole bands: the kernel shifts the last band up -- unless the whole bands fill the 512 resident
+        // slots exactly; then the whole bands here and the ragged rest (fewer than R2 rows, real halo row above) in a second launch
+        // (the second launch costs ~10 us: only where the first one is long -- 16384 x 16390 0.1076 ms this way, 0.1146 on the one-strip kernel;
+        //  16384 x 8200 would be 0.068 against 0.059, so smaller frames fall through to the one-strip kernel instead)
+        const bool overflow2 = band_ok && wanted && rows > R2 && stream_core::shifted_band_overflows(gx2, rows, R2, 2, gh_num_cu());
+        if (overflow2 && (long long)width * rows >= (long long)GH_LAB_INT("GH_SOBEL_SPLIT_MIN_PX", 1 << 28)) {
+            if (hw) return GH_NO_FLAG_FORM;
+            const int main_rows = rows - rows % R2;
+            if (int rc = gh_sobel_rows_halo_wait(src, dst, width, main_rows, top_is_border, 0, stream, nullptr, luma)) return rc;
+            return gh_sobel_rows_halo_wait(src + (size_t)main_rows * width, dst + (size_t)main_rows * width, width, rows - main_rows, 0, bottom_is_border, stream, nullptr, luma);
+        }
+        if (band_ok && rows >= R2 && !overflow2 && wanted) {                            // (a ragged last band is shifted up inside the kernel)
+            if (hw && hw->pad) return GH_OK;      // probe: k_sobel_dma2 will run
+            stream_core::BandPlan p2 = stream_core::make_band_plan(rows, R2, -1, 0, -1, 0);
+            p2.order = stream_core::sanitize_order(order_knob % 1000, p2.bands, gx2, gh_num_xcd());
+            const unsigned g2 = (unsigned)stream_core::plan_grid(p2, gx2);
+            bool launched = false;
+#ifdef GH_ENABLE_PROBES
+            const int nsd = luma ? 33 : GH_LAB_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: NOTES.md)
+            launched = true;
+            if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);     // regular-band form, other depths
+            else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else if (unal == 1 && !luma) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else if (unal == 2 && !luma) k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            else launched = false;
+            if (launched) gh_note_kernel(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
+#endif
+            if (!launched && unal == 0) {
+                note(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
+                if (luma == 1) k_sobel_dma2<3, 1, 1, 0, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                else if (luma == 2) k_sobel_dma2<3, 1, 1, 0, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                else k_sobel_dma2<3, 1, 1, 0, 0><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                launched = true;
+            }
+            if (launched) {
+                GH_LAUNCH_CHECK();
+                return GH_OK;
+            }
+        }
+    }
+    if (hw && hw->pad) return GH_OK;              // probe: k_sobel_dma will run
+    const int u1 = unal < 0 ? 0 : unal;           // (dma_unal == 1, probe builds: pieces from the strip's own unaligned address, UNAL = 0 code)
+    // Regular-band (branch-free) form of the one-strip kernel, 128-134 VGPRs: every band has R + 2 input rows in whole chunks of 6.
+    // With 16-row bands -- the mid-size and small frames, where a wave's row step is latency-bound and the generic form's scalar
+    // branches count -- it is 7-20 % faster (7680 x 4352 0.0198 vs 0.0249 ms, 4096^2 0.0115 vs 0.0129, 16384 x 1024 0.0117 vs 0.0134,
+    // 3840 x 2160 0.0108 vs 0.0119, 1920 x 1088 0.0100 vs 0.0107); with 64-row bands on large frames it only lets a third workgroup
+    // onto each CU and loses 1.5-5 % (16384^2, 32768 x 8192), so those keep the generic form.
+    const bool reg1 = GH_LAB_INT("GH_SOBEL_REG", 1) && dma == 3 && sp == 2 && R == 16 && rows >= R && plan.n[1] == 0 && plan.order < 1000 &&
+                      !stream_core::shifted_band_overflows(groups_x, rows, R, 3, gh_num_cu());
+    auto launch_dma = [&](auto unal_c, auto reg_c) {
+        constexpr int U = decltype(unal_c)::value, RG = decltype(reg_c)::value;
+        if (luma == 1) k_sobel_dma<3, 0, 2, 1, U, RG, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        else if (luma == 2) k_sobel_dma<3, 0, 2, 1, U, RG, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        else k_sobel_dma<3, 0, 2, 1, U, RG, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    };
+    using std::integral_constant;
+    if (dma == 3 && sp == 2) {                    // what ships: ring depth 3, nontemporal stores
+        note(reg1 ? (u1 ? "k_sobel_dma regular R=16 unaligned" : "k_sobel_dma regular R=16") : (u1 ? "k_sobel_dma unaligned" : "k_sobel_dma"));
+        if (reg1) {
+            if (u1 == 0) launch_dma(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+            else if (u1 == 1) launch_dma(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+            else launch_dma(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        } else {
+            if (u1 == 0) launch_dma(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            else if (u1 == 1) launch_dma(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+            else launch_dma(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+        }
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+#ifdef GH_ENABLE_PROBES
+    GH_REQUIRE(!luma, "luma on load: ring depth 3 and nontemporal stores only");
+    gh_note_kernel(u1 ? "k_sobel_dma unaligned" : "k_sobel_dma");
+    if (u1 && sp == 0) {
+        if (u1 == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    }
+    else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW
+        const int rw = dma - 100, skew = GH_LAB_INT("GH_SOBEL_SKEW", 3);
+        const unsigned gm = (unsigned)((rows + 4 * rw - 1) / (4 * rw));
+        if (rw == 4) k_march_probe<4><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+        else if (rw == 6) k_march_probe<6><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+        else if (rw == 8) k_march_probe<8><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+        else if (rw == 14) k_march_probe<14><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+        else k_march_probe<2><<<gm, b, 0, s>>>(src, dst, width, rows, skew);
+    }
+    else if (dma >= 200 && dma < 1800 && (dma % 100 >= 2 && dma % 100 <= 4) && width % (dma >= 1700 ? 4096 : 1024 * (dma / 100) * (dma >= 1600 ? 1 : (dma >= 800 ? 2 : 4))) == 0 && rows % R == 0) {
+        // wide-strip probe: dma = 100 * KiB per wave and row + ring depth (8 and 16 KiB: two / one wave per workgroup)
+        const int pieces = dma >= 1700 ? 1 : dma / 100, wpb = pieces >= 16 ? 1 : (pieces >= 8 ? 2 : 4), gxw = width / (1024 * pieces * wpb);
+        stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+        pw.order = stream_core::sanitize_order(order_knob, pw.bands, gxw, gh_num_xcd());
+        const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
+        if (dma == 203) k_wide_strip_probe<2, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 202) k_wide_strip_probe<2, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 403) k_wide_strip_probe<4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 402) k_wide_strip_probe<4, 2><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 803) k_wide_strip_probe<8, 3, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 802) k_wide_strip_probe<8, 2, 2><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 1703) k_loader_probe<3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);      // 17xx: the loader-wave probe (4 KiB per workgroup and row)
+        else if (dma == 1704) k_loader_probe<4><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 1603) k_wide_strip_probe<16, 3, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 1602) k_wide_strip_probe<16, 2, 1><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else GH_REQUIRE(false, "wide-strip probe: unknown size / depth");
+    }
+    else if (dma >= 30000 && dma < 40000 && width % 12288 == 0 && rows % R == 0) {
+        // 3:1 wide-strip probe on a plane of 3 x 16384 bytes per row: dma = 30000 + 100 * KiB read per wave and row + ring depth
+        const int pieces = (dma - 30000) / 100, depth = dma % 100, wpb = pieces >= 12 ? (depth == 3 ? 1 : 2) : (pieces >= 6 ? (depth == 3 ? 2 : 4) : 4);
+        const int gxw = width / (1024 * pieces * wpb);
+        stream_core::BandPlan pw = stream_core::make_band_plan(rows, R, -1, 0, -1, 0);
+        pw.order = stream_core::sanitize_order(GH_LAB_INT("GH_SOBEL_ORDER", 6), pw.bands, gxw, gh_num_xcd());
+        const unsigned gw = (unsigned)stream_core::plan_grid(pw, gxw);
+        if (dma == 30302) k_wide_strip_probe<3, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 30303) k_wide_strip_probe<3, 3, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 30602) k_wide_strip_probe<6, 2, 4, 3><<<gw, 256, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 30603) k_wide_strip_probe<6, 3, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 31202) k_wide_strip_probe<12, 2, 2, 3><<<gw, 128, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else if (dma == 31203) k_wide_strip_probe<12, 3, 1, 3><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
+        else GH_REQUIRE(false, "3:1 wide-strip probe: unknown size / depth");
+    }
+    else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no sqrt (wrong results)
+    else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no arithmetic (wrong results)
+    else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // probe: row-synchronous workgroup
+    else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // the same without arithmetic
+    else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);  // probe: default-policy DMA loads
+    else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
     GH_LAUNCH_CHECK();
     return GH_OK;
+#else
+    return gh_set_error(GH_ERR_ARG, "unreachable: the release library has one ring depth and one store policy");
+#endif
 }
 
 extern "C" {

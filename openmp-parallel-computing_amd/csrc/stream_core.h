@@ -251,6 +251,52 @@ __device__ __forceinline__ f32x2 half2_reg()
     return h;
 }
 
+// ---- luma in packed f32 (fused kernel: RGB -> luma; plane Sobel of a later pass: grey -> luma) ---------------------------------------
+// luma of two pixels as integer-valued floats (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): trunc(y) == (float)(unsigned char)y for
+// 0 <= y <= 255; same arithmetic as gh_luma (gh_common.h; monolithic/src/parallel_to_grayscale.c:13), minus the float -> int -> float
+// round trip.  IEEE mode must not be contracted; the FMA mode uses explicit fused multiply-adds.  Needs MODE.fp_round = nearest-even.
+template <int MODE>
+__device__ __forceinline__ f32x2 luma_f2(f32x2 r, f32x2 g, f32x2 b)
+{
+#pragma clang fp contract(off)
+    const f32x2 cr = {0.299f, 0.299f}, cg = {0.587f, 0.587f}, cb = {0.114f, 0.114f};
+    f32x2 y;
+    if (MODE == GH_MODE_FMA) {
+        f32x2 t = cg * g;
+        t = __builtin_elementwise_fma(cr, r, t);
+        y = __builtin_elementwise_fma(cb, b, t);
+    } else {
+        const f32x2 s = cr * r + cg * g;
+        y = s + cb * b;
+    }
+    y.x = opaque(__builtin_truncf(y.x));
+    y.y = opaque(__builtin_truncf(y.y));
+    return y;
+}
+
+// One strip row of a PLANE for the packed-f32 core: this lane's 16 pixels (q), the dword holding pixel x-1 in its top byte (ql) and the one
+// holding pixel x+16 in its low byte (qr) -> the pair layout G[m] = (p[m-1], p[m+7]), m = 0..9, that rowf2 consumes.
+// LUMA = 0: the bytes as they are (sobel_edge on a luma plane, monolithic/src/sobel.c:6-25).
+// LUMA = 1 / 2 ("luma on load"): every byte e goes through lum(e, e, e) first, IEEE / FMA arithmetic -- what pass k + 1 of the reference's
+// driver loop does to pass k's replicated edge image before it filters it (monolithic/src/main_with_sobel.c:54-62: convert_to_grayscale of
+// (e, e, e), plane extract, sobel_edge).  lum(e, e, e) is not e: 13 grey levels come out one lower (IEEE: 37, 61, 74, ...; tests hold the
+// list), so the step cannot be skipped -- but it can ride on the load instead of costing a 2 B/px pass of its own.  Kernels that use it
+// must leave MODE.fp_round at nearest-even (the luma sums round) and take rowf2's RTZ = 0 tail.
+template <int LUMA>
+__device__ __forceinline__ void plane_row_pairs(const uint4 &q, uint32_t ql, uint32_t qr, f32x2 (&G)[10])
+{
+    const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};          // own pixels 0..7 live in q.x, q.y and 8..15 in q.z, q.w
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+        if (LUMA) G[m + 1] = luma_f2<LUMA - 1>(G[m + 1], G[m + 1], G[m + 1]);
+    }
+    f32x2 E = {opaque((float)(ql >> 24)), opaque((float)(qr & 0xffu))};      // the two pixels just outside the lane's 16
+    if (LUMA) E = luma_f2<LUMA - 1>(E, E, E);
+    G[0] = f32x2{E.x, G[8].x};
+    G[9] = f32x2{G[1].y, E.y};
+}
+
 // streaming (read-once / write-once) 16-byte accesses: `nt` keeps these lines from displacing reusable data in L2
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_stream(const uint4 *p)

@@ -230,6 +230,26 @@ def sobel(plane, out=None):
     return out
 
 
+def sobel_of_gray(edge_plane, mode: int = MODE_IEEE, out=None):
+    """Pass k >= 2 of the reference's gray + Sobel loop in one launch (gh_sobel_of_gray_u8_dev): (h, w) edge plane of the previous
+    pass -> Sobel of lum(e, e, e), border = 0.  Equals sobel(gray_of_plane(edge_plane, mode)) at half the traffic."""
+    import torch
+    h, w = edge_plane.shape
+    if out is None:
+        out = torch.empty_like(edge_plane)
+    check(abi.load().gh_sobel_of_gray_u8_dev(_dev_ptr(edge_plane), _dev_ptr(out), w, h, mode, _stream()), "sobel_of_gray")
+    return out
+
+
+def sobel_of_gray_rows(buf, out, rows: int, mode: int, top_is_border: bool, bottom_is_border: bool):
+    """Band form: `buf` is (rows+2, w) of EDGE rows (rows 1..rows the band, 0 / rows+1 the neighbours' edge rows); `out` is (rows, w)."""
+    w = buf.shape[1]
+    assert buf.shape[0] == rows + 2 and tuple(out.shape) == (rows, w)
+    check(abi.load().gh_sobel_of_gray_u8_rows_dev(_dev_ptr(buf) + w, _dev_ptr(out), w, rows, mode, int(top_is_border),
+                                                  int(bottom_is_border), _stream()), "sobel_of_gray_rows")
+    return out
+
+
 def last_kernel() -> str:
     """Which device-kernel form this thread's last Sobel / fused / convolution launch took (gh_last_kernel)."""
     return abi.load().gh_last_kernel().decode()

@@ -55,6 +55,10 @@ class HipBackend:
     def fused_rows(self, buf, out, rows, top_is_border, bottom_is_border):
         return self.api.gray_sobel_fused_rows(buf, out, rows, self.mode, top_is_border, bottom_is_border)
 
+    def sobel_of_gray_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        """Sobel of lum(e, e, e) of a band of EDGE rows (a later pass of the multi-pass pipeline), one launch."""
+        return self.api.sobel_of_gray_rows(buf, out, rows, self.mode, top_is_border, bottom_is_border)
+
     def sum_rgb(self, rgb):
         return self.api.sum_rgb_dev(rgb)
 
@@ -193,7 +197,7 @@ class NativeHaloComm:
     def bind_pipeline_gray_sobel(self, img_buf, gray_ws, edge_ws, rows, passes, mode):
         import torch
         w, c = img_buf.shape[1], img_buf.shape[2]
-        assert img_buf.shape[0] == rows + 2 and tuple(gray_ws.shape) == (rows + 2, w) and tuple(edge_ws.shape) == (rows, w)
+        assert img_buf.shape[0] == rows + 2 and tuple(gray_ws.shape) == (rows + 2, w) and tuple(edge_ws.shape) == (rows + 2, w)
         assert img_buf.is_contiguous() and gray_ws.is_contiguous() and edge_ws.is_contiguous()
         fn, chk, h = self.lib.gh_sharded_pipeline_gray_sobel_dev, self.abi.check, self.handle
         img, g, e = img_buf.data_ptr(), gray_ws.data_ptr(), edge_ws.data_ptr()
@@ -618,24 +622,29 @@ class ShardedPipelineGraySobel:
     """One rank's share of the reference's multi-pass driver loop -- `passes` x (gray, extract, Sobel, replicate),
     monolithic/src/main_with_sobel.c:49-76 -- on a row-sharded frame, in place in `img` (rows+2, width, channels; rows
     1..rows = the shard).  Pass k+1 filters what pass k wrote, so there is ONE halo exchange per pass: an RGB row before pass 1
-    (the fused kernel recomputes the halo luma), the luma row lum(e, e, e) of the neighbours' edge rows before every later pass
-    (not the identity: 13 grey levels move in IEEE mode).  run(passes) returns the last pass's edge plane (rows, width)."""
+    (the fused kernel recomputes the halo luma), the neighbours' raw EDGE rows before every later pass -- the plane Sobel applies
+    lum(e, e, e) on load (not the identity: 13 grey levels move in IEEE mode), one launch and 2 B/px per pass.  The edge planes of
+    successive passes alternate between two (rows+2, width) work planes; run(passes) returns the last pass's edge plane (rows, width)."""
 
     def __init__(self, geom: ShardGeometry, backend, device, channels: int = 3, group=None, native_comm=None):
         import torch
         self.g, self.backend, self.channels = geom, backend, channels
         rows = geom.rows
         self.img = torch.zeros((rows + 2, geom.width, channels), dtype=torch.uint8, device=device)
-        self.gray = torch.zeros((rows + 2, geom.width), dtype=torch.uint8, device=device)
-        self.edge = torch.zeros((rows, geom.width), dtype=torch.uint8, device=device)
+        self.planes = [torch.zeros((rows + 2, geom.width), dtype=torch.uint8, device=device) for _ in range(2)]      # [0]: where the last pass lands
         self._native_comm = native_comm if (rows and native_comm is not None and geom.world > 1 and not geom.has_empty_shards) else None
         self._native = {}
         self._halo_img = _RowHalo(geom, self.img, group)
-        self._halo_gray = _RowHalo(geom, self.gray, group)
+        self._halo_plane = [_RowHalo(geom, p, group) for p in self.planes]
 
     @property
     def shard(self):
         return self.img[1:self.g.rows + 1]
+
+    @property
+    def edge(self):
+        """The last run()'s edge plane, (rows, width)."""
+        return self.planes[0][1:self.g.rows + 1]
 
     def result(self):
         """The last run()'s edge plane for the HOST: synchronises, then checks the communicator (see ShardedFusedGraySobel.result)."""
@@ -653,22 +662,22 @@ class ShardedPipelineGraySobel:
         if self._native_comm is not None:
             fn = self._native.get(passes)
             if fn is None:
-                fn = self._native[passes] = self._native_comm.bind_pipeline_gray_sobel(self.img, self.gray, self.edge, rows, passes, getattr(b, "mode", 0))
+                fn = self._native[passes] = self._native_comm.bind_pipeline_gray_sobel(self.img, self.planes[1], self.planes[0], rows, passes, getattr(b, "mode", 0))
             fn()
             return self.edge
-        luma = self.gray[1:rows + 1]
         for p in range(passes):
+            o, i = (passes - 1 - p) & 1, (passes - p) & 1          # pass p writes planes[o]: the last pass lands in planes[0]
+            out = self.planes[o][1:rows + 1]
             if p == 0 and self.channels >= 3:
                 self._halo_img()
-                b.fused_rows(self.img, self.edge, rows, g.top_is_border, g.bottom_is_border)
+                b.fused_rows(self.img, out, rows, g.top_is_border, g.bottom_is_border)
                 continue
             if p == 0:
-                b.extract_plane(self.shard, luma)                 # channels 1 / 2: the plane is channel 0
-            elif self.channels >= 3:
-                b.gray_of_plane(self.edge, luma)
+                b.extract_plane(self.shard, self.planes[i][1:rows + 1])          # channels 1 / 2: the plane is channel 0
+            self._halo_plane[i]()                                                 # a luma row (pass 1, 1 / 2 channels) or the neighbours' raw edge rows
+            if p > 0 and self.channels >= 3:
+                b.sobel_of_gray_rows(self.planes[i], out, rows, g.top_is_border, g.bottom_is_border)
             else:
-                luma.copy_(self.edge)
-            self._halo_gray()
-            b.sobel_rows(self.gray, self.edge, rows, g.top_is_border, g.bottom_is_border)
+                b.sobel_rows(self.planes[i], out, rows, g.top_is_border, g.bottom_is_border)
         b.replicate_plane(self.edge, self.shard)
         return self.edge

@@ -110,3 +110,31 @@ def test_historic_wrappers_refuse_frames_that_are_not_three_channel(pkg):
         api.old_parallel_convolution(np.zeros((6, 7, 3), np.int64), [1] * 9, np.zeros((4, 5, 4), np.int64), 9)
     with pytest.raises(pkg.GrayHipError):
         api.old_parallel_convolution(np.zeros((6, 7, 4), np.int64), [1] * 9, np.zeros((4, 5, 3), np.int64), 9)
+
+
+RELEASE_ENV_KNOBS = {"GH_SHARD_STEP_FORM", "GH_HALO_WAIT_MS", "GRAYHIP_MODE", "GRAYHIP_DEVICE", "GRAYHIP_VERBOSE"}
+
+
+def _env_names(path):
+    data = open(path, "rb").read()
+    return {m.decode() for m in re.findall(rb"\b(?:GH|GRAYHIP)_[A-Z][A-Z0-9_]{2,}\b", data)} - {"GH_API", "GH_OK"}
+
+
+def test_release_library_reads_only_the_documented_knobs(pkg):
+    """`make lib` is the release build: the measurement lab's tuning knobs (GH_SOBEL_*, GH_FUSED_*, GH_CONV_*, ...) and the kernel variants
+    they select are compiled out -- the only environment names in libgrayhip.so are the five INTEGRATION.md documents (the drop-in CLIs
+    add GRAYHIP_SERVER and GRAYHIP_PNG, abi.py GRAYHIP_LIB).  The probe build (`make probes`) is where the lab lives."""
+    names = _env_names(pkg.abi.LIB_PATH)
+    assert names == RELEASE_ENV_KNOBS, sorted(names ^ RELEASE_ENV_KNOBS)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in sorted(RELEASE_ENV_KNOBS | {"GRAYHIP_SERVER", "GRAYHIP_PNG", "GRAYHIP_LIB"}):
+        assert n in doc, f"{n} is not documented in INTEGRATION.md"
+    if os.path.exists(pkg.abi.LAB_LIB_PATH):
+        lab = _env_names(pkg.abi.LAB_LIB_PATH)
+        assert len(lab) >= 40 and RELEASE_ENV_KNOBS <= lab
+        assert os.path.getsize(pkg.abi.LIB_PATH) < 0.6 * os.path.getsize(pkg.abi.LAB_LIB_PATH)
+        # the probe build exports the same C ABI (tests and tools swap the two freely)
+        for name in pkg.abi.SIGNATURES:
+            assert hasattr(ctypes.CDLL(pkg.abi.LAB_LIB_PATH), name), name
+    for sym in ("k_sobel_dma4", "k_sobel_tiled", "k_wide_strip_probe", "k_gray_sobel_fused", "k_march_probe"):
+        assert sym.encode() not in open(pkg.abi.LIB_PATH, "rb").read(), f"{sym} (a variant that lost its A/B) is in the release library"

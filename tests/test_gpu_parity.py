@@ -226,6 +226,7 @@ def test_fused_equals_two_kernels(pkg, oracle, torch_mod, w, h, ch):
                                    {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "0"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "36"}, {"GH_FUSED_DMA_R": "8", "GH_FUSED_DMA_ORDER": "8"}, {"GH_FUSED_DMA_R": "16", "GH_FUSED_DMA_ORDER": "2008"}, {"GH_FUSED_DMA_ORDER": "2006"},
                                    {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "34"}, {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "64"},
                                    {"GH_FUSED_REG": "2", "GH_FUSED_DMA": "3", "GH_FUSED_DMA_R": "22", "GH_FUSED_DMA_PAD_KB": "30"}])
+@pytest.mark.lab
 def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     """Every tuning variant of the fused kernel (register-staged, LDS-DMA ring depths, band plans) is bit-exact too.
     tests/conftest.py sets GH_TUNE_DYNAMIC so that the library re-reads the knobs on every launch."""
@@ -244,6 +245,7 @@ def test_fused_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
                                    {"GH_SOBEL_R": "24", "GH_SOBEL_ORDER": "2"}, {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "1234"},
                                    {"GH_SOBEL_R": "40", "GH_SOBEL_ORDER": "1010"}, {"GH_SOBEL_R": "128", "GH_SOBEL_ORDER": "4"},
                                    {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "6"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "36"}, {"GH_SOBEL_R": "8", "GH_SOBEL_ORDER": "8"}, {"GH_SOBEL_R": "16", "GH_SOBEL_ORDER": "2008"}, {"GH_SOBEL_ORDER": "2000"}])
+@pytest.mark.lab
 def test_sobel_alternative_paths(pkg, oracle, torch_mod, knobs, monkeypatch):
     """Register-staged and LDS-DMA forms of the plane Sobel kernel, every ring depth: bit-exact, including bands
     (halo rows above / below) and the shifted last strip of widths that are not a multiple of 1024."""
@@ -321,6 +323,7 @@ def test_host_pointer_shims(pkg, oracle, jpg_crop, cli_crop):
     assert np.array_equal(rgba[..., 0], cli_crop["gray_rgba_p1_c0"]) and np.array_equal(rgba[..., 3], cli_crop["rgba_alpha"])
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h,c,passes", [(2048, 1100, 3, 1), (2000, 1237, 4, 3), (4096, 1025, 3, 2)])
 def test_host_shim_chunked_pipeline(pkg, oracle, w, h, c, passes, monkeypatch):
     """Large frames go through convert_to_grayscale's host entry point in chunks (an uploader thread copies chunk k+1 up while chunk
@@ -338,6 +341,7 @@ def test_host_shim_chunked_pipeline(pkg, oracle, w, h, c, passes, monkeypatch):
     assert np.array_equal(buf, oracle.gray_inplace(img, 0))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h", [(2048, 1100), (1999, 1237), (4096, 1025), (16384, 200), (1024, 2049)])
 def test_host_shim_chunked_sobel_edge(pkg, oracle, w, h, monkeypatch):
     """Large planes go through sobel_edge's host entry point in row chunks (upload of chunk k+1 overlaps the filter on the rows
@@ -380,6 +384,7 @@ def test_conv3x3_signed_kernel_and_small_frames(pkg, oracle, torch_mod):
             assert np.array_equal(pkg.hostapi.conv3x3(d, k, norm).cpu().numpy(), oracle.conv3x3(img, k, norm)), (w, h, k)
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h", [(342, 7), (343, 70), (344, 5), (350, 130), (1024, 67), (1365, 9), (1366, 33), (2731, 66), (5461, 20), (5464, 3), (683, 1), (700, 2)])
 def test_conv3x3_ring_kernel_any_width_and_alignment(pkg, oracle, torch_mod, w, h, monkeypatch):
     """Rows of 1024 bytes and more (3 w >= 1024) run the LDS-DMA ring kernel k_conv3x3_dma whatever the width and the base
@@ -404,6 +409,70 @@ def test_conv3x3_ring_kernel_any_width_and_alignment(pkg, oracle, torch_mod, w, 
         monkeypatch.setenv("GH_CONV_DMA", "0")            # register-staged strips (aligned frames) / per-pixel kernel
         assert np.array_equal(pkg.hostapi.conv3x3(dev(t, img), k, norm).cpu().numpy(), want), (k, norm, "no dma")
         monkeypatch.delenv("GH_CONV_DMA")
+
+
+SOG_SHAPES = [(16384, 130), (16384, 64), (8192, 192), (4096, 70), (2048, 16), (1920, 1080), (1024, 40), (1040, 33), (3072, 1), (2064, 3),
+              (1031, 70), (2037, 100), (4099, 35), (16370, 40), (512, 20), (100, 30), (16, 3), (7, 5), (333, 77), (2, 2), (1, 9)]
+
+
+@pytest.mark.parametrize("w,h", SOG_SHAPES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sobel_of_gray_is_pass_k_of_the_reference_loop(pkg, oracle, torch_mod, w, h, mode):
+    """gh_sobel_of_gray_u8_dev: pass k >= 2 of monolithic/src/main_with_sobel.c:51-62 in one launch -- the previous pass's edge plane e
+    goes through lum(e, e, e) ON LOAD and then through the 3x3 window.  Against the oracle's convert_to_grayscale of (e, e, e) + plane
+    extract + sobel_edge, for every kernel form the launcher picks (two strips / one strip, regular and generic bands, dword-shifted and
+    byte-shifted rows, register-staged strips + column tail, per-pixel), both arithmetic modes.  The plane holds every grey level many
+    times, the 13 (IEEE) / 13 (FMA) levels that lum() moves in particular."""
+    t = torch_mod
+    rs = np.random.RandomState(w * 31 + h)
+    e = rs.randint(0, 256, (h, w)).astype(np.uint8)
+    e[h // 2, : min(w, 256)] = np.arange(min(w, 256), dtype=np.uint8)          # every level next to its neighbours
+    luma = oracle.gray_to_plane(np.repeat(e[:, :, None], 3, axis=2), mode)
+    assert (luma != e).any() or w * h < 64
+    want = oracle.sobel(luma)
+    got = pkg.hostapi.sobel_of_gray(dev(t, e), mode)
+    assert np.array_equal(got.cpu().numpy(), want), pkg.hostapi.last_kernel()
+    assert "luma-on-load" in pkg.hostapi.last_kernel()
+    # == the two launches it replaces
+    two = pkg.hostapi.sobel(pkg.hostapi.gray_of_plane(dev(t, e), mode))
+    assert t.equal(got, two)
+    # row bands with halo rows: a partition of the frame == the whole frame
+    if h >= 3:
+        out = t.full((h, w), 0x5A, dtype=t.uint8, device="cuda")
+        full = dev(t, e)
+        for y0, y1 in pkg.sharding.row_partition(h, 3):
+            if y1 == y0:
+                continue
+            top, bot = y0 == 0, y1 == h
+            buf = t.full((y1 - y0 + 2, w), 0xEE, dtype=t.uint8, device="cuda")      # halo rows poisoned where the band edge is the frame border
+            buf[1:y1 - y0 + 1] = full[y0:y1]
+            if not top:
+                buf[0] = full[y0 - 1]
+            if not bot:
+                buf[y1 - y0 + 1] = full[y1]
+            pkg.hostapi.sobel_of_gray_rows(buf, out[y0:y1], y1 - y0, mode, top, bot)
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_sobel_of_gray_full_size(pkg, oracle, known, torch_mod):
+    """BASELINE's size: pass 2 of the pipeline on the 16384^2 known-answer frame.  The edge plane of pass 1 is pinned by the compiled
+    reference's SHA-256; pass 2 in one launch must equal gray_of_plane + Sobel (both pinned kernels) bit for bit, in both modes, and
+    run the two-strip ring kernel."""
+    t = torch_mod
+    img = oracle.frame_rand(16384, 16384, 3, seed=1)
+    edge1 = pkg.hostapi.gray_sobel_fused(dev(t, img), 0)
+    assert sha(edge1) == known["IEEE"]["rand1_16384"]["edge"]
+    del img
+    for mode in (0, 1):
+        one = pkg.hostapi.sobel_of_gray(edge1, mode)
+        assert pkg.hostapi.last_kernel() == "k_sobel_dma2 regular R=64 luma-on-load"
+        two = pkg.hostapi.sobel(pkg.hostapi.gray_of_plane(edge1, mode))
+        assert t.equal(one, two)
+        assert not bool(one[0].any()) and not bool(one[-1].any()) and not bool(one[:, 0].any()) and not bool(one[:, -1].any())
+        # and a band of it against the oracle
+        e_np = edge1[5000:5066].cpu().numpy()
+        want = oracle.sobel(oracle.gray_to_plane(np.repeat(e_np[:, :, None], 3, axis=2), mode))[1:-1]
+        assert np.array_equal(one[5001:5065].cpu().numpy(), want)
 
 
 def test_gray_of_plane_moves_13_levels(pkg, known, torch_mod):
@@ -533,9 +602,21 @@ def test_native_comm_self_exchange(pkg, native_comm, torch_mod):
 
 
 @pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (4096, 2), (16384, 130), (16384, 2048), (1031, 70), (8192, 128), (512, 20), (16384, 64), (4096, 1)])
-@pytest.mark.parametrize("form", [2, 1, 0])
+@pytest.mark.parametrize("form", [2, 1])
 @pytest.mark.parametrize("lb", LOOPBACK_MODES)
 def test_native_sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, lb):
+    _sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, lb)
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("w,h", [(1024, 40), (2064, 3), (16384, 130), (1031, 70), (512, 20)])
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_native_sharded_steps_loopback_event_form(pkg, oracle, lab_comm, torch_mod, w, h, lb):
+    """form 0 (exchange || interior rows, then two edge-row launches behind an event): the slowest form measured, probe builds only"""
+    _sharded_steps_loopback(pkg, oracle, lab_comm, torch_mod, w, h, 0, lb)
+
+
+def _sharded_steps_loopback(pkg, oracle, native_comm, torch_mod, w, h, form, lb):
     """The C++ sharded step in its three forms -- 2 halo flag (default: exchange on the side stream beside ONE launch whose first /
     last band wait for a flag inside the kernel), 1 serial (exchange on the caller's stream, then one launch), 0 overlapped with
     events (exchange || interior rows, then first / last row) -- as each of the three kinds of shard a multi-GPU job has: a middle
@@ -703,6 +784,7 @@ def test_native_batched_halo_prefetch_loopback(pkg, oracle, native_comm, torch_m
 @pytest.mark.parametrize("w,h,c", [(1031, 40, 3), (2063, 70, 4), (1047, 3, 3), (33, 9, 3), (4099, 2, 4), (7, 5, 3), (1029, 66, 3), (2049, 17, 3),
                                    (1025, 5, 3), (1025, 67, 4), (1026, 130, 3), (3073, 65, 3), (2037, 90, 3), (16370, 24, 3),
                                    (2052, 40, 3), (1044, 9, 3), (16380, 24, 3), (5000, 33, 3), (1039, 66, 4), (1028, 35, 4), (1030, 7, 3)])
+@pytest.mark.lab
 @pytest.mark.parametrize("dma_unaligned", ["2", "1", "0"])
 def test_fused_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, c, dma_unaligned, monkeypatch):
     """The fused C entry point takes any width.  Widths >= 1024: the LDS-DMA ring kernel itself -- GH_FUSED_DMA_UNALIGNED=2
@@ -772,6 +854,7 @@ def test_streamed_row_blocks_equal_whole_frame(pkg, oracle):
 
 @pytest.mark.parametrize("w,h", [(2048, 16), (2048, 64), (2064, 32), (4096, 128), (4112, 48), (6144, 64), (8192, 192), (8208, 16), (16384, 64), (16384, 80),
                                  (10240, 256), (16400, 128)])
+@pytest.mark.lab
 @pytest.mark.parametrize("band_rows", ["", "16", "64"])
 def test_sobel_two_strips_per_wave(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
     """k_sobel_dma2: a wave owns two neighbouring 1 KiB strips of every row (aligned frames whose rows split into whole bands of 64 or
@@ -838,8 +921,74 @@ def test_headline_shapes_run_the_kernels_they_are_meant_to_run(pkg, torch_mod):
     assert api.last_kernel() == "k_conv3x3_dma regular"
     api.conv3x3(t.zeros((100, 5000, 3), dtype=t.uint8, device="cuda"), [1] * 9, 9)
     assert api.last_kernel() == "k_conv3x3_dma regular unaligned"
+    # pass k of the multi-pass loop: the plane Sobel's forms with the luma applied on load
+    for (w, h), want in (((16384, 16384), "k_sobel_dma2 regular R=64"), ((16384, 2048), "k_sobel_dma2 regular R=16"), ((1920, 1080), "k_sobel_dma regular R=16"),
+                         ((2037, 1362), "k_sobel_dma regular R=16 unaligned"), ((640, 480), "k_sobel_stream")):
+        api.sobel_of_gray(t.zeros((h, w), dtype=t.uint8, device="cuda"), 0)
+        assert api.last_kernel() == want + " luma-on-load"
 
 
+def test_release_library_ignores_the_labs_knobs(pkg, oracle, known, torch_mod, monkeypatch):
+    """The library callers get is the one this suite runs: no tuning knob is read.  With the lab's knobs set to values that would send a
+    probe build to its slowest / probe-only forms, the release library launches the same kernels as without them and reproduces the
+    compiled reference's known answers at BASELINE's 4096^2 size."""
+    t, api = torch_mod, pkg.hostapi
+    img = oracle.frame_rand(4096, 4096, 3, seed=1)
+    d = dev(t, img)
+
+    def run():
+        names = []
+        edge = api.gray_sobel_fused(d, 0)
+        names.append(api.last_kernel())
+        gray = api.gray_to_plane(d, 0)
+        e2 = api.sobel(gray)
+        names.append(api.last_kernel())
+        api.conv3x3(d, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16)
+        names.append(api.last_kernel())
+        api.sobel_of_gray(e2, 0)
+        names.append(api.last_kernel())
+        return names, sha(edge), sha(gray), sha(e2)
+
+    plain = run()
+    assert plain[0][0].startswith("k_fused_dma") and plain[0][1].startswith("k_sobel_dma") and plain[0][2].startswith("k_conv3x3_dma")
+    assert plain[1] == plain[3] == known["IEEE"]["rand1_4096"]["edge"] and plain[2] == known["IEEE"]["rand1_4096"]["gray"]
+    for k, v in {"GH_SOBEL_DMA": "0", "GH_FUSED_DMA": "0", "GH_SOBEL_NS": "4", "GH_SOBEL_R": "7", "GH_FUSED_DMA_R": "5", "GH_SOBEL_IMPL": "tile",
+                 "GH_FUSED_IMPL": "tile", "GH_SOBEL_CORE": "i16", "GH_CONV_DMA": "0", "GH_CONV_IMPL": "px", "GH_SOBEL_ST": "0", "GH_FUSED_DMA_ST": "12",
+                 "GH_NUM_CU_OVERRIDE": "8", "GH_BAND_ALIAS_RULE": "0", "GH_SOBEL_ORDER": "0", "GH_HALO_MEMOPS": "3"}.items():
+        monkeypatch.setenv(k, v)
+    assert run() == plain
+
+
+@pytest.mark.lab
+def test_release_and_probe_builds_pick_the_same_kernels(pkg, oracle, torch_mod):
+    """One source tree, two builds: with no knob set the probe build (whose knobs are environment reads) and the release library (whose knobs
+    are their defaults, folded at compile time) must choose the same kernel form for every shape -- and produce the same bytes."""
+    t, api = torch_mod, pkg.hostapi
+    rs = np.random.RandomState(20261005)
+    shapes = [(16384, 2048), (16384, 130), (12288, 200), (8192, 4101), (4096, 4100), (2037, 1362), (1920, 1080), (16370, 200), (1031, 70), (640, 480), (100, 30), (7, 5)]
+    shapes += [(int(rs.randint(1, 9000)), int(rs.randint(1, 300))) for _ in range(30)]
+    lab_lib = pkg.abi.load()
+    assert lab_lib._name == pkg.abi.LAB_LIB_PATH
+    for w, h in shapes:
+        img = t.from_numpy(oracle.frame_rand(w, h, 3, seed=w + h)).cuda()
+        plane = img[:, :, 0].contiguous()
+        got = {}
+        for which in ("lab", "release"):
+            ctx = pkg.abi.use_library(pkg.abi.LIB_PATH if which == "release" else pkg.abi.LAB_LIB_PATH)
+            with ctx:
+                api.init(0)
+                res = []
+                res.append((api.gray_sobel_fused(img, 0), api.last_kernel()))
+                res.append((api.sobel(plane), api.last_kernel()))
+                res.append((api.sobel_of_gray(plane, 0), api.last_kernel()))
+                res.append((api.conv3x3(img, [1, 2, 1, 2, 4, 2, 1, 2, 1], 16), api.last_kernel()))
+                got[which] = res
+        for (a, ka), (b, kb) in zip(got["lab"], got["release"]):
+            assert ka == kb, (w, h, ka, kb)
+            assert t.equal(a, b), (w, h, ka)
+
+
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h,band_rows", [(4096, 70, ""), (2048, 17, ""), (8192, 200, "64"), (8192, 65, "64"), (6160, 47, "16"), (2050, 35, "")])
 def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_rows, monkeypatch):
     """Rows that do not split into whole bands: k_sobel_dma2 shifts its last band up to end at the frame edge (the shared rows are
@@ -855,6 +1004,7 @@ def test_sobel_two_strips_ragged_last_band(pkg, oracle, torch_mod, w, h, band_ro
     assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane)[1:h + 1])
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h", [(4096, 64), (4096, 130), (8192, 192), (16384, 64), (16384, 80), (4112, 64), (12288, 131), (5008, 70)])
 @pytest.mark.parametrize("depth,core,band_rows", [("3", "1", ""), ("3", "0", ""), ("6", "1", ""), ("2", "1", "32"), ("3", "1", "16"), ("2", "0", "16")])
 def test_sobel_four_strips_per_wave(pkg, oracle, torch_mod, w, h, depth, core, band_rows, monkeypatch):
@@ -878,6 +1028,7 @@ def test_sobel_four_strips_per_wave(pkg, oracle, torch_mod, w, h, depth, core, b
     assert np.array_equal(out.cpu().numpy(), oracle.sobel(plane[1:])[:h])
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h", [(8192, 4101), (8192, 4111), (16384, 2050)])
 def test_sobel_two_strips_split_into_two_launches(pkg, oracle, torch_mod, w, h, monkeypatch):
     """Frames whose whole bands fill the resident workgroup slots exactly and that have a few rows more: a shifted extra band would add
@@ -903,6 +1054,7 @@ def test_sobel_two_strips_split_into_two_launches(pkg, oracle, torch_mod, w, h, 
     assert np.array_equal(pkg.hostapi.sobel(d[1:h + 1].contiguous()).cpu().numpy(), oracle.sobel(plane[1:h + 1]))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("w,h", [(2048, 16), (2049, 16), (2050, 32), (2051, 16), (2052, 48), (2060, 64), (4100, 32), (4099, 128), (6147, 16), (16370, 32), (16380, 64)])
 def test_sobel_two_strips_per_wave_unaligned_rows(pkg, oracle, torch_mod, w, h, monkeypatch):
     """k_sobel_dma2 on frames whose rows are not 16-byte aligned (aligned-down pieces, dword-shifted landing, byte re-alignment of
@@ -1046,6 +1198,7 @@ def test_many_passes(pkg, oracle, torch_mod, w, h, c):
 
 @pytest.mark.parametrize("w,h", [(1031, 40), (2063, 70), (1040 + 7, 3), (33, 9), (4099, 2), (1025, 5), (1026, 67), (1027, 130), (1028, 3),
                                  (2049, 70), (3073, 65), (2037, 90), (16370, 24), (2052, 40), (1044, 9), (16380, 24), (5000, 33), (1039, 66)])
+@pytest.mark.lab
 @pytest.mark.parametrize("dma_unaligned", ["2", "1", "0"])
 def test_sobel_widths_that_are_not_multiples_of_16(pkg, oracle, torch_mod, w, h, dma_unaligned, monkeypatch):
     """Frame widths that are not a multiple of 16 (rows start at unaligned bytes).  Widths >= 1024: the LDS-DMA ring kernel --

@@ -12,6 +12,7 @@ from conftest import ROOT
 
 @pytest.mark.gpu
 def test_lds_dma_kernels_under_latency_noise():
+    # (the tool switches to the probe build itself: its knob sets select ring depths, band heights and dispatch orders)
     spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(ROOT, "tools", "stress_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -49,6 +49,12 @@ class OracleBackend:
         luma = torch.from_numpy(self.O.gray_to_plane(buf.numpy(), self.mode))
         return self.sobel_rows(luma, out, rows, top_is_border, bottom_is_border)
 
+    def sobel_of_gray_rows(self, buf, out, rows, top_is_border, bottom_is_border):
+        """a later pass of the multi-pass pipeline: the band holds EDGE rows, the filter sees lum(e, e, e)"""
+        e = buf.numpy()
+        luma = torch.from_numpy(self.O.gray_to_plane(np.repeat(e[:, :, None], 3, axis=2), self.mode))
+        return self.sobel_rows(luma, out, rows, top_is_border, bottom_is_border)
+
     def sum_rgb(self, rgb):
         return self.O.sum_rgb(rgb.numpy())
 

@@ -3,12 +3,13 @@
 
 usage: ab_fused.py [--op fused|sobel|gray] [--w W] [--h H] [--rounds N] "NAME=K1:V1,K2:V2" ...
 Each variant is a set of environment knobs (GH_TUNE_DYNAMIC makes the library re-read them per launch).
-The probe variants (GH_FUSED_DMA_ST other than 2, GH_SOBEL_DMA=13) exist only in a library built with
-`make lib HIPFLAGS_EXTRA=-DGH_ENABLE_PROBES`.
+Runs against the probe build (`make probes` -> build_probes/libgrayhip_probes.so): the release library reads no tuning knob.
 """
 import argparse, importlib, os, sys, hashlib, statistics
 os.environ["GH_TUNE_DYNAMIC"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the knobs exist in the probe build only (`make probes`); GRAYHIP_LIB=<path> to time another build
+os.environ.setdefault("GRAYHIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_probes", "libgrayhip_probes.so"))
 import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--op", default="fused"); ap.add_argument("--w", type=int, default=16384); ap.add_argument("--h", type=int, default=0)

@@ -26,6 +26,8 @@ add("gray_sobel_fused_rgba8", 5, lambda: api.gray_sobel_fused(rgba, 0, out=plane
 add("extract_plane_rgb8", 4, lambda: api.extract_plane(rgb, out=plane))
 add("replicate_plane_rgb8", 4, lambda: api.replicate_plane(plane, out3))
 add("gray_of_plane", 2, lambda: api.gray_of_plane(plane, 0, out=plane2))
+add("sobel_of_gray_u8 (pass k)", 2, lambda: api.sobel_of_gray(plane, 0, out=plane2))
+add("sobel_of_gray_u8 (FMA mode)", 2, lambda: api.sobel_of_gray(plane, 1, out=plane2))
 sums = torch.zeros(3, dtype=torch.int64, device="cuda")
 lib = pkg.abi.load()
 add("sum_rgb8", 3, lambda: pkg.abi.check(lib.gh_sum_rgb8_dev(rgb.data_ptr(), npix, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)))

@@ -27,6 +27,9 @@ def main():
         r = RECIPES[name]
         path = os.path.join(outdir, name + ".txt")
         env = dict(os.environ, **{k: str(v) for k, v in r.get("env", {}).items()})
+        # the recipes turn GH_* tuning knobs: those exist in the probe build only (`make probes`); "lib": "release" in a recipe = the shipped library
+        if r.get("lib", "probes") == "probes":
+            env.setdefault("GRAYHIP_LIB", os.path.join(ROOT, "build_probes", "libgrayhip_probes.so"))
         with open(path, "w") as f:
             f.write(f"# {name}: {r['what']}\n")
             for cmd in r["cmds"]:
