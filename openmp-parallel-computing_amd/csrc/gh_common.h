@@ -32,6 +32,7 @@ int gh_set_error(int status, const char *fmt, ...);
     } while (0)
 
 int gh_ensure_init();   // lazy gh_init(GRAYHIP_DEVICE or 0)
+int gh_sobel_init_tables(int device);   // sobel.hip: the device's lum(v, v, v) table of the luma-on-load kernels (called by gh_init)
 
 // which device kernel form the last launch of this thread took (gh_last_kernel(): tests and bench.py assert that the headline shapes run
 // the kernels DESIGN.md says they run, instead of silently falling to a slower form)

@@ -65,7 +65,7 @@ int do_init(int device)
     int xcc = 0;
     g_num_xcd = (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xcc > 0) ? xcc : GH_REF_NUM_XCD;
     (void)hipGetLastError();
-    return GH_OK;
+    return gh_sobel_init_tables(device);
 }
 
 // The two streams of the chunked host pipelines (upload | kernel + download), created once per process.  Both or neither: a call

@@ -31,8 +31,10 @@ using namespace sobel_tile;
 // MODE.fp_round = toward zero: this kernel has no rounding-sensitive float op (all sums are exact integers).
 template <int R, int C, int CORE, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w,
-                                                                    int rows, int groups_x, int zero_top, int zero_bot, int ws)
+                                                                    int rows, int groups_x, int zero_top, int zero_bot, int ws, const uint8_t *lum_lut)
 {
+    __shared__ uint8_t lut[LUMA ? 256 : 4];
+    if (LUMA) stream_core::load_lum_lut(lut, lum_lut);
     // w: frame width = row pitch (rows need not be 16-byte aligned: the vector accesses below are then unaligned, which
     // gfx950 global memory instructions handle); ws <= w, a multiple of 16: the columns covered by strips.  Columns
     // [ws, w) of a frame whose width is not a multiple of 16 are left to k_sobel_px_cols.
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
     const int x = xw + 16 * lane;
     const int y0 = gy_i * R;
     static_assert(LUMA == 0 || CORE == 1, "luma on load: packed-f32 core only");
-    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const float half = half_reg();
     const f32x2 half2 = {half, half};
     const bool in_frame = x < ws;
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
                 out = (j & 1) ? row16<1>(st16, q[j], ql, qr, half) : row16<0>(st16, q[j], ql, qr, half);
             } else {
                 f32x2 G[10];
-                plane_row_pairs<LUMA>(q[j], ql, qr, G);
-                out = (j & 1) ? rowf2<1, LUMA == 0>(stf, G, half2) : rowf2<0, LUMA == 0>(stf, G, half2);
+                plane_row_pairs<LUMA>(q[j], ql, qr, G, lut);
+                out = (j & 1) ? rowf2<1, 1>(stf, G, half2) : rowf2<0, 1>(stf, G, half2);
             }
             if (i >= 2) {
                 const int y = y0 + i - 2;
@@ -132,9 +134,12 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_stream(const uint8
 // its two neighbours are re-aligned in registers, six v_alignbyte_b32 with the row's (wave-uniform) s.
 template <int D, int PROBE = 0, int SP = 2, int LP = 1, int UNAL = 0, int REG = 0, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
-                                                                 int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
+                                                                 int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw,
+                                                                 const uint8_t *lum_lut)
 {
     using namespace stream_core;
+    __shared__ uint8_t lut[LUMA ? 256 : 4];
+    if (LUMA) load_lum_lut(lut, lum_lut);
     constexpr int PRE = UNAL ? 16 : 0;                           // UNAL: 16 bytes in front of the lane grid (the piece may land up to 16 early)
     constexpr int SLOT = UNAL ? 16 + STRIP_PX + 32 : STRIP_PX + 16;   // one strip row + the halo dword pair / + pre-area and 32-byte tail
     constexpr int CHK = (D % 2 == 0) ? D : 2 * D;                // unroll: slot = j % D and h2 ring parity = j & 1 are static
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
     // LAST row it requests, and the wait for the exchange sits right in front of that request
     const bool up = band_walks_up(plan, gy_i) || (hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows);
     if (hw.flag) gh_halo_started(hw);
-    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
     // halo dwords: lane 0 -> the 4 bytes ending at the strip's first byte (pixel xw-1 = its byte 3),
@@ -259,8 +264,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             qr >>= 8u * sh;
         }
         f32x2 G[10];
-        plane_row_pairs<LUMA>(q, ql, qr, G);
-        uint4 out = (j & 1) ? rowf2<1, LUMA == 0, PROBE == 1>(st, G, half2) : rowf2<0, LUMA == 0, PROBE == 1>(st, G, half2);
+        plane_row_pairs<LUMA>(q, ql, qr, G, lut);
+        uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
         if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
         if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
@@ -315,9 +320,12 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
 // dword-shifted (1), plus the byte re-alignment of both strips (2) -- exactly k_sobel_dma's scheme on a 2 KiB row.
 template <int D, int LB = 1, int REG = 0, int UNAL = 0, int LUMA = 0>
 __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows,
-                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw)
+                                                                  int groups_x, stream_core::BandPlan plan, int zero_top, int zero_bot, GhHaloWait hw,
+                                                                  const uint8_t *lum_lut)
 {
     using namespace stream_core;
+    __shared__ uint8_t lut[LUMA ? 256 : 4];
+    if (LUMA) load_lum_lut(lut, lum_lut);
     constexpr int SW = 2 * STRIP_PX;
     constexpr int PRE = UNAL ? 16 : 0;
     constexpr int SLOT = UNAL ? 16 + SW + 32 : SW + 16;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
     // sharded step, halo-flag form (gh_common.h; see k_fused_dma): first band upward, the wait in front of the halo row's request
     const bool up = hw.flag && !zero_top && y0 == 0 && y0 + nrows - 2 < rows;
     if (hw.flag) gh_halo_started(hw);
-    if (LUMA == 0) __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz); luma on load rounds to nearest
+    __builtin_amdgcn_s_setreg(0x0801, 3);   // MODE.fp_round(f32) = toward zero for the whole kernel (see mag_pack_rtz)
     const f32x2 half2 = half2_reg();
     const uint32_t voff = (uint32_t)xw + (uint32_t)lane * 16u;
     uint32_t hoff = lane == 0 ? (uint32_t)xw - 4u : (uint32_t)(xw + SW);
@@ -422,8 +430,8 @@ __global__ __launch_bounds__(stream_core::BLOCK, LB) void k_sobel_dma2(const uin
                 qr >>= 8u * sh;
             }
             f32x2 G[10];
-            plane_row_pairs<LUMA>(q, ql, qr, G);
-            uint4 out = (j & 1) ? rowf2<1, LUMA == 0>(st, G, half2) : rowf2<0, LUMA == 0>(st, G, half2);
+            plane_row_pairs<LUMA>(q, ql, qr, G, lut);
+            uint4 out = (j & 1) ? rowf2<1, 1>(st, G, half2) : rowf2<0, 1>(st, G, half2);
             if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {       // y < rows by construction of nrows
                 if (SUB == 0) out.x &= first_col_mask;               // the frame's first / last column is border: written as 0
                 if (SUB == 1) out.w &= last_col_mask;
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(BLOCK) void k_sobel_tiled(const uint8_t *__restrict
 
 // One pixel per lane; rows above/below the band are read only when they exist.  x0 > 0: only the columns [x0, w) (the last w % 16 columns of a
 // frame whose width is not a multiple of 16: the strip kernel covers the rest).  LUMA = 1 / 2: every byte read goes through lum(e, e, e)
-// first (stream_core::plane_row_pairs explains why), here with the scalar gh_luma of gh_common.h.
+// first (stream_core::plane_row_pairs explains why), here with the scalar gh_luma of gh_common.h itself (IEEE / FMA arithmetic).
 template <int LUMA>
 __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_px(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int rows, int x0,
                                                                 int zero_top, int zero_bot)
@@ -881,6 +889,17 @@ __global__ void k_selftest_mag(int variant, unsigned long long *mismatches)
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// ---- the luma-on-load table: lum(v, v, v) for v = 0..255, row 0 in IEEE arithmetic, row 1 in FMA arithmetic -- filled ON THE DEVICE by
+// gh_luma itself (the function every gray kernel uses, pinned by the compiled reference over all 2^24 triples), once per device
+__device__ uint8_t g_lum_lut[2][256];
+
+__global__ void k_fill_lum_lut()
+{
+    const uint32_t v = threadIdx.x & 255u;
+    g_lum_lut[0][v] = (uint8_t)gh_luma<GH_MODE_IEEE>(v, v, v);
+    g_lum_lut[1][v] = (uint8_t)gh_luma<GH_MODE_FMA>(v, v, v);
+}
+
 }  // namespace
 
 extern "C" {
@@ -908,6 +927,29 @@ int gh_sobel_of_gray_u8_dev(const uint8_t *src, uint8_t *dst, int width, int hei
 
 }  // extern "C"
 
+// Called by gh_init for the device it selects (shim.hip): fills the table there, on the null stream, and remembers its address.
+static const uint8_t *g_lum_lut_addr[64] = {};
+int gh_sobel_init_tables(int device)
+{
+    uint8_t *base = nullptr;
+    GH_HIP_TRY(hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_lum_lut)));
+    k_fill_lum_lut<<<1, 256, 0, nullptr>>>();
+    GH_LAUNCH_CHECK();
+    GH_HIP_TRY(hipDeviceSynchronize());
+    if (device >= 0 && device < 64) g_lum_lut_addr[device] = base;
+    return GH_OK;
+}
+
+// device address of the 256-byte table row for `luma` (1 IEEE, 2 FMA) on the current device
+static int lum_lut_row(int luma, const uint8_t **row)
+{
+    int dev = 0;
+    GH_HIP_TRY(hipGetDevice(&dev));
+    GH_REQUIRE(dev >= 0 && dev < 64 && g_lum_lut_addr[dev], "the luma table of this device was never initialised (gh_init selects the device)");
+    *row = g_lum_lut_addr[dev] + 256 * (luma - 1);
+    return GH_OK;
+}
+
 // The launcher of every plane-Sobel entry point.
 // hw != nullptr: the halo-flag form of the sharded step (gh_common.h) -- only the LDS-DMA ring kernels carry the wait; a frame that would
 // run another form (or the two-launch split of k_sobel_dma2) is refused with GH_NO_FLAG_FORM before anything is launched.
@@ -925,6 +967,9 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
     if (int rc = gh_ensure_init()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int zt = top_is_border ? 1 : 0, zb = bottom_is_border ? 1 : 0;
+    const uint8_t *lut = nullptr;          // luma on load: the 256-byte table row of the arithmetic mode (device memory)
+    if (luma)
+        if (int rc = lum_lut_row(luma, &lut)) return rc;
     const bool aligned = width % 16 == 0 && gh_aligned16(src) && gh_aligned16(dst);
     bool use_tile = false;
     int core = 1;
@@ -951,7 +996,8 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
     // the last width % 16 columns.  (All per-pixel: 0.69 ms on 16370 x 16384; this way: 0.125 ms.)
     const int ws = width & ~15;
     // (small unaligned frames stay on the single per-pixel launch: 1921 x 1081 takes 7 us that way, 11 us as strips + tail)
-    const int dma = GH_LAB_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (probe builds: 0 = register-staged kernel, other depths, probes)
+    // (luma on load exists for the shipped forms only: in probe builds it ignores the ring-depth and store-policy knobs)
+    const int dma = luma ? 3 : GH_LAB_INT("GH_SOBEL_DMA", 3);      // LDS-DMA ring depth (probe builds: 0 = register-staged kernel, other depths, probes)
     // The LDS-DMA kernel takes ANY width >= 1024 and any base alignment: a DMA piece is 64 lanes x 16 B from consecutive global
     // addresses that need no alignment (only the LDS side is lane-linear), every strip is full (the last one is shifted left
     // to end at the frame edge), so a row pitch that is not a multiple of 16 changes nothing but the address arithmetic --
@@ -997,10 +1043,9 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
         note(ws < width ? "k_sobel_stream + k_sobel_px" : "k_sobel_stream");
 #define GH_SOBEL_STREAM(R_)                                                                                                        \
         do {                                                                                                                         \
-            if (luma == 1) k_sobel_stream<R_, 2, 1, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                  \
-            else if (luma == 2) k_sobel_stream<R_, 2, 1, 2><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);             \
-            else if (GH_LAB && core == 0) k_sobel_stream<R_, 2, GH_LAB ? 0 : 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);   \
-            else k_sobel_stream<R_, 2, 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws);                            \
+            if (luma) k_sobel_stream<R_, 2, 1, 1><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws, lut);                   \
+            else if (GH_LAB && core == 0) k_sobel_stream<R_, 2, GH_LAB ? 0 : 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws, nullptr);   \
+            else k_sobel_stream<R_, 2, 1, 0><<<g, b, 0, s>>>(src, dst, width, rows, groups_x, zt, zb, ws, nullptr);                   \
         } while (0)
         switch (R) {
         case 64: GH_SOBEL_STREAM(64); break;
@@ -1028,7 +1073,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
     // rewritten launch after launch (74.7 % vs 66.7 %): the 256 MB Infinity Cache absorbs the writes and they never
     // reach HBM.  With the output rotating over six planes it is the other way round (sc1 62.6 %, plain 60.7 %,
     // nt 66.8 %; tools/ab_fused.py --out-ring 6), and nt performs the same in both settings.
-    const int sp = GH_LAB_INT("GH_SOBEL_ST", 2);        // 2 nt; probe builds: 0 plain, 1 sc1
+    const int sp = luma ? 2 : GH_LAB_INT("GH_SOBEL_ST", 2);        // 2 nt; probe builds: 0 plain, 1 sc1
     // Two strips per wave (k_sobel_dma2, regular-band form): frames whose rows split into whole bands of 64 or 16 rows
     // and that are wide and tall enough to give every SIMD a wave.  Measured against the one-strip kernel (tools/sweep.py r2_ai,
     // sweep.py r2_aj): 16384^2 0.0952 vs 0.1000 ms, 32768 x 8192 0.0944 vs 0.0972, shards of 8192 / 4096 / 2048 rows 0.0498 vs
@@ -1092,21 +1137,20 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
 #ifdef GH_ENABLE_PROBES
             const int nsd = luma ? 33 : GH_LAB_INT("GH_SOBEL_NS_D", 33);          // other ring depths / the generic band form (register counts: NOTES.md)
             launched = true;
-            if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-            else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-            else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-            else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);     // regular-band form, other depths
-            else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-            else if (unal == 1 && !luma) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-            else if (unal == 2 && !luma) k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+            if (nsd == 2) k_sobel_dma2<2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
+            else if (nsd == 3) k_sobel_dma2<3><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
+            else if (nsd == 4) k_sobel_dma2<4><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
+            else if (nsd == 22 && (R2 + 2) / 2 >= 4) k_sobel_dma2<2, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);     // regular-band form, other depths
+            else if (nsd == 66 && (R2 + 2) / 6 >= 4) k_sobel_dma2<6, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
+            else if (unal == 1 && !luma) k_sobel_dma2<3, 1, 1, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
+            else if (unal == 2 && !luma) k_sobel_dma2<3, 1, 1, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
             else launched = false;
             if (launched) gh_note_kernel(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
 #endif
             if (!launched && unal == 0) {
                 note(R2 == 64 ? "k_sobel_dma2 regular R=64" : "k_sobel_dma2 regular R=16");
-                if (luma == 1) k_sobel_dma2<3, 1, 1, 0, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                else if (luma == 2) k_sobel_dma2<3, 1, 1, 0, 2><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
-                else k_sobel_dma2<3, 1, 1, 0, 0><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv);
+                if (luma) k_sobel_dma2<3, 1, 1, 0, 1><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, lut);
+                else k_sobel_dma2<3, 1, 1, 0, 0><<<g2, b, pad, s>>>(src, dst, width, rows, gx2, p2, zt, zb, hwv, nullptr);
                 launched = true;
             }
             if (launched) {
@@ -1126,9 +1170,8 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
                       !stream_core::shifted_band_overflows(groups_x, rows, R, 3, gh_num_cu());
     auto launch_dma = [&](auto unal_c, auto reg_c) {
         constexpr int U = decltype(unal_c)::value, RG = decltype(reg_c)::value;
-        if (luma == 1) k_sobel_dma<3, 0, 2, 1, U, RG, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-        else if (luma == 2) k_sobel_dma<3, 0, 2, 1, U, RG, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-        else k_sobel_dma<3, 0, 2, 1, U, RG, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        if (luma) k_sobel_dma<3, 0, 2, 1, U, RG, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, lut);
+        else k_sobel_dma<3, 0, 2, 1, U, RG, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
     };
     using std::integral_constant;
     if (dma == 3 && sp == 2) {                    // what ships: ring depth 3, nontemporal stores
@@ -1149,11 +1192,11 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
     GH_REQUIRE(!luma, "luma on load: ring depth 3 and nontemporal stores only");
     gh_note_kernel(u1 ? "k_sobel_dma unaligned" : "k_sobel_dma");
     if (u1 && sp == 0) {
-        if (u1 == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-        else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+        if (u1 == 1) k_sobel_dma<3, 0, 0, 1, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+        else k_sobel_dma<3, 0, 0, 1, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
     }
-    else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-    else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma == 3 && sp == 1) k_sobel_dma<3, 0, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+    else if (dma == 3 && sp == 0) k_sobel_dma<3, 0, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
     else if (dma >= 100 && dma < 200 && width % stream_core::STRIP_PX == 0) {     // band-march probe: dma = 100 + RW, GH_SOBEL_SKEW
         const int rw = dma - 100, skew = GH_LAB_INT("GH_SOBEL_SKEW", 3);
         const unsigned gm = (unsigned)((rows + 4 * rw - 1) / (4 * rw));
@@ -1196,16 +1239,16 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
         else if (dma == 31203) k_wide_strip_probe<12, 3, 1, 3><<<gw, 64, 0, s>>>(src, dst, width, rows, gxw, pw);
         else GH_REQUIRE(false, "3:1 wide-strip probe: unknown size / depth");
     }
-    else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no sqrt (wrong results)
-    else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);        // timing probe: no arithmetic (wrong results)
-    else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // probe: row-synchronous workgroup
-    else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);   // the same without arithmetic
-    else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);  // probe: default-policy DMA loads
-    else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-    else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-    else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-    else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
-    else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv);
+    else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);        // timing probe: no sqrt (wrong results)
+    else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);        // timing probe: no arithmetic (wrong results)
+    else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);   // probe: row-synchronous workgroup
+    else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);   // the same without arithmetic
+    else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);  // probe: default-policy DMA loads
+    else if (dma == 22) k_sobel_dma<2, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+    else if (dma <= 2) k_sobel_dma<2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+    else if (dma == 4) k_sobel_dma<4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+    else if (dma <= 6) k_sobel_dma<6><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
+    else k_sobel_dma<8><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);
     GH_LAUNCH_CHECK();
     return GH_OK;
 #else

@@ -277,24 +277,42 @@ __device__ __forceinline__ f32x2 luma_f2(f32x2 r, f32x2 g, f32x2 b)
 // One strip row of a PLANE for the packed-f32 core: this lane's 16 pixels (q), the dword holding pixel x-1 in its top byte (ql) and the one
 // holding pixel x+16 in its low byte (qr) -> the pair layout G[m] = (p[m-1], p[m+7]), m = 0..9, that rowf2 consumes.
 // LUMA = 0: the bytes as they are (sobel_edge on a luma plane, monolithic/src/sobel.c:6-25).
-// LUMA = 1 / 2 ("luma on load"): every byte e goes through lum(e, e, e) first, IEEE / FMA arithmetic -- what pass k + 1 of the reference's
-// driver loop does to pass k's replicated edge image before it filters it (monolithic/src/main_with_sobel.c:54-62: convert_to_grayscale of
-// (e, e, e), plane extract, sobel_edge).  lum(e, e, e) is not e: 13 grey levels come out one lower (IEEE: 37, 61, 74, ...; tests hold the
-// list), so the step cannot be skipped -- but it can ride on the load instead of costing a 2 B/px pass of its own.  Kernels that use it
-// must leave MODE.fp_round at nearest-even (the luma sums round) and take rowf2's RTZ = 0 tail.
+// LUMA = 1 ("luma on load"): every byte e is replaced by lum(e, e, e) first -- what pass k + 1 of the reference's driver loop does to pass
+// k's replicated edge image before it filters it (monolithic/src/main_with_sobel.c:54-62: convert_to_grayscale of (e, e, e), plane
+// extract, sobel_edge).  lum(e, e, e) is not e: 13 grey levels come out one lower (IEEE: 37, 61, 74, ...; the FMA build moves another
+// 13; tests hold both lists), so the step cannot be skipped -- but it can ride on the load instead of costing a 2 B/px pass of its own.
+// It is a function of ONE byte, so it is a 256-entry table: `lut` points at 256 bytes in LDS which the workgroup copied from the device
+// table that gh_luma itself filled (sobel.hip, k_fill_lum_lut), and a pixel costs one byte extract, one ds_read_u8 and one conversion --
+// 9 VALU instructions per pixel for the whole row step against 12.4 with the five packed-f32 operations and the truncation of the
+// arithmetic spelt out (measured first: 0.1194 ms at 16384^2 in IEEE mode, 0.1135 in FMA mode), no rounding-sensitive float operation
+// in the kernel (MODE.fp_round stays toward-zero, rowf2's cheaper tail) and one code path for both arithmetic modes.
 template <int LUMA>
-__device__ __forceinline__ void plane_row_pairs(const uint4 &q, uint32_t ql, uint32_t qr, f32x2 (&G)[10])
+__device__ __forceinline__ void plane_row_pairs(const uint4 &q, uint32_t ql, uint32_t qr, f32x2 (&G)[10], const uint8_t *lut)
 {
     const uint32_t lo[2] = {q.x, q.y}, hi[2] = {q.z, q.w};          // own pixels 0..7 live in q.x, q.y and 8..15 in q.z, q.w
+    if (LUMA) {
+        uint32_t a[8], c[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
-        if (LUMA) G[m + 1] = luma_f2<LUMA - 1>(G[m + 1], G[m + 1], G[m + 1]);
+        for (int m = 0; m < 8; ++m) { a[m] = lut[gh_byte(lo[m >> 2], m & 3)]; c[m] = lut[gh_byte(hi[m >> 2], m & 3)]; }     // all 18 reads in flight together
+        const uint32_t el = lut[ql >> 24], er = lut[qr & 0xffu];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) G[m + 1] = f32x2{opaque((float)a[m]), opaque((float)c[m])};
+        G[0] = f32x2{opaque((float)el), G[8].x};
+        G[9] = f32x2{G[1].y, opaque((float)er)};
+        return;
     }
-    f32x2 E = {opaque((float)(ql >> 24)), opaque((float)(qr & 0xffu))};      // the two pixels just outside the lane's 16
-    if (LUMA) E = luma_f2<LUMA - 1>(E, E, E);
-    G[0] = f32x2{E.x, G[8].x};
-    G[9] = f32x2{G[1].y, E.y};
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        G[m + 1] = f32x2{opaque((float)gh_byte(lo[m >> 2], m & 3)), opaque((float)gh_byte(hi[m >> 2], m & 3))};
+    G[0] = f32x2{opaque((float)(ql >> 24)), G[8].x};
+    G[9] = f32x2{G[1].y, opaque((float)(qr & 0xffu))};
+}
+
+// the workgroup's copy of the 256-byte luma table (every thread of the 256 brings one byte; call before any wave leaves the kernel)
+__device__ __forceinline__ void load_lum_lut(uint8_t *lut_lds, const uint8_t *lut_global)
+{
+    lut_lds[threadIdx.x & 255] = lut_global[threadIdx.x & 255];
+    __syncthreads();
 }
 
 // streaming (read-once / write-once) 16-byte accesses: `nt` keeps these lines from displacing reusable data in L2
