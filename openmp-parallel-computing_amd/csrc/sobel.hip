@@ -220,7 +220,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
             const uint32_t dm = uniform_u32(d + PRE + (a & 3u) - ap);
             glds_row1k_tail(dm, dm + STRIP_PX, uniform_ptr(A - ap), (uint32_t)lane * 16u, lane == 0 ? t0 : t1, slot);
         } else {
-            glds_row1k_halo<LP>(d, d + STRIP_PX, strip_row(i) - xw, voff, hoff, slot);      // always exactly 2 vector-memory instructions
+            if (PROBE == 5) glds_row1k_nohalo(d, d + STRIP_PX, strip_row(i) - xw, voff, hoff, slot);      // probe: what do the two 4-byte halo requests per row cost?
+            else glds_row1k_halo<LP>(d, d + STRIP_PX, strip_row(i) - xw, voff, hoff, slot);      // always exactly 2 vector-memory instructions
         }
     };
 #pragma unroll
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         const bool issue = KIND == 0 ? i + D - 1 < nrows : (KIND == 4 ? j + D - 1 < CHK : true);     // KIND 3 / 4: regular bands, see k_sobel_dma2
         if (issue) {
             issue_row(i + D - 1, (j + D - 1) % D);
-            if (KIND == 2 || KIND == 4) wait_vm<3 * (D - 1)>(j % D); else wait_vm<2 * (D - 1)>(j % D);
+            constexpr int NLD = PROBE == 5 ? 1 : 2;                   // vector-memory instructions per ring row
+            if (KIND == 2 || KIND == 4) wait_vm<(NLD + 1) * (D - 1)>(j % D); else wait_vm<NLD * (D - 1)>(j % D);
         } else {
             wait_vm<0>(j % D);
         }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(stream_core::BLOCK) void k_sobel_dma(const uint8_t 
         f32x2 G[10];
         plane_row_pairs<LUMA>(q, ql, qr, G, lut);
         uint4 out = (j & 1) ? rowf2<1, 1, PROBE == 1>(st, G, half2) : rowf2<0, 1, PROBE == 1>(st, G, half2);
-        if (PROBE == 2 || PROBE == 4) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
+        if (PROBE == 2 || PROBE == 4 || PROBE == 5) out = make_uint4(q.x ^ hh.x, q.y, q.z, q.w ^ hh.y);   // timing probe: the kernel's access pattern without its arithmetic
         if (KIND == 3 ? j >= 2 : (KIND != 0 || i >= 2)) {           // y = y0 + i - 2 < rows by construction of nrows
             const int y = up ? y0 + nrows - 1 - i : y0 + i - 2;
             out.x &= first_col_mask;                                 // the frame's first / last column is border: written as 0
@@ -1241,6 +1243,7 @@ int gh_sobel_rows_halo_wait(const uint8_t *src, uint8_t *dst, int width, int row
     }
     else if (dma == 13) k_sobel_dma<3, 1><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);        // timing probe: no sqrt (wrong results)
     else if (dma == 33) k_sobel_dma<3, 2><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);        // timing probe: no arithmetic (wrong results)
+    else if (dma == 63) k_sobel_dma<3, 5><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);        // the same without the halo dword requests (what do they cost?)
     else if (dma == 43 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 3><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);   // probe: row-synchronous workgroup
     else if (dma == 53 && width % 4096 == 0 && rows % 64 == 0) k_sobel_dma<3, 4><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);   // the same without arithmetic
     else if (dma == 23) k_sobel_dma<3, 0, 2, 0><<<g, b, pad, s>>>(src, dst, width, rows, groups_x, plan, zt, zb, hwv, nullptr);  // probe: default-policy DMA loads

@@ -479,6 +479,14 @@ __device__ __forceinline__ void glds_row1k_halo(uint32_t lds_slot, uint32_t lds_
     if (LP == 0) asm volatile(GH_GLDS_HEAD GH_PIECE("", "") GH_GLDS_HALO GH_GLDS_OPS);     // default policy: probe only
     else asm volatile(GH_GLDS_HEAD GH_PIECE("", " nt") GH_GLDS_HALO GH_GLDS_OPS);
 }
+// probe only (k_sobel_dma PROBE = 5): the 1 KiB piece WITHOUT the halo dword pair -- one vector-memory instruction per row
+__device__ __forceinline__ void glds_row1k_nohalo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt ; gh_dma slot=%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rowb), "s"(lds_slot), "i"(slot) : "memory");
+    (void)lds_halo; (void)hoff;
+}
 // 2 KiB row (two neighbouring u8 plane strips owned by one wave: k_sobel_dma2)
 __device__ __forceinline__ void glds_row2k_halo(uint32_t lds_slot, uint32_t lds_halo, const uint8_t *rowb, uint32_t voff, uint32_t hoff, int slot)
 {
