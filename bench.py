@@ -92,6 +92,9 @@ def parse_args():
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity checks")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step bracket of `value` is repeated this many times in all (the first one is `value`); min / median / max in `repeats`")
+    ap.add_argument("--edge-ring", type=int, default=3,
+                    help="N = 1: the fused (value) region writes its edge plane into this many planes in rotation (default 3: 805 MB of output, beyond the "
+                         "256 MB Infinity Cache; 1 = one plane rewritten every step, the A/B)")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed run-in before the W warm-up steps: after ~2 ms of load the GPU's power management dips the clocks and "
                          "takes 30-60 ms to settle (tools/drift_start.py: launches 10-40 of a burst run 25-40 %% slower); "
@@ -665,15 +668,20 @@ def main() -> int:
     if single:
         # ================================ one GPU =========================================================================
         luma = torch.zeros((rows + 2, W), dtype=torch.uint8, device=device)
-        edge = torch.empty((rows, W), dtype=torch.uint8, device=device)
+        # The value region's output rotates over THREE edge planes (805 MB in all): one 268 MB plane rewritten step after step would fit the
+        # 256 MB Infinity Cache almost whole, and FETCH_SIZE / WRITE_SIZE count fabric requests including its hits (MI355X_MICROARCH.md) --
+        # `--edge-ring 1` is the A/B against that (profiles/r4_ab/fused_edge_ring.txt: the same within noise, the stores being nontemporal).
+        edge_ring = [torch.empty((rows, W), dtype=torch.uint8, device=device) for _ in range(max(args.edge_ring, 1))]
+        edge = edge_ring[0]
         rgb_ptr, edge_ptr, luma_ptr = rgb.data_ptr(), edge.data_ptr(), luma.data_ptr()
+        edge_ring_ptr, n_ring = [t.data_ptr() for t in edge_ring], len(edge_ring)
         s_ptr = stream.cuda_stream
         chk = pkg.abi.check
 
         def step_fused(k, ev):
             if ev:
                 ev[0].record(stream)
-            chk(lib.gh_gray_sobel_fused_rows_dev(rgb_ptr, edge_ptr, W, rows, 3, mode, 1, 1, s_ptr), "fused")
+            chk(lib.gh_gray_sobel_fused_rows_dev(rgb_ptr, edge_ring_ptr[k % n_ring], W, rows, 3, mode, 1, 1, s_ptr), "fused")
             if ev:
                 ev[-1].record(stream)
 
@@ -723,8 +731,12 @@ def main() -> int:
         if not args.no_check:
             if is_known_frame and KA:
                 want_in, want_edge = KA["frames"]["rand1_16384"]["in"], KA[ka_mode]["rand1_16384"]["edge"]
-                got_in, got_edge = sha256_of(rgb), sha256_of(edge)
-                check = "ok: full-frame SHA-256 of input and edge plane == compiled reference" if (got_in == want_in and got_edge == want_edge) \
+                got_in = sha256_of(rgb)
+                ring_planes = edge_ring if fused else [edge]                  # every plane the timed steps wrote
+                got_edges = [sha256_of(e_) for e_ in ring_planes]
+                got_edge = got_edges[0] if all(g_ == want_edge for g_ in got_edges) else next(g_ for g_ in got_edges if g_ != want_edge)
+                check = f"ok: full-frame SHA-256 of input and of {'all ' + str(len(ring_planes)) + ' edge planes' if len(ring_planes) > 1 else 'the edge plane'} == compiled reference" \
+                    if (got_in == want_in and got_edge == want_edge) \
                     else f"MISMATCH (input {'ok' if got_in == want_in else got_in[:16]}, edge {'ok' if got_edge == want_edge else got_edge[:16]})"
             else:
                 try:
@@ -775,7 +787,7 @@ def main() -> int:
             if not luma[1:rows + 1].any():                                   # (the split pipeline was the FIRST region or did not run)
                 chk(lib.gh_gray_rgb8_to_plane_dev(rgb_ptr, luma_ptr + W, rows * W, 3, mode, s_ptr), "gray")
             lumas = [luma, luma.clone(), luma.clone()]
-            edges = [edge, torch.empty_like(edge), torch.empty_like(edge)]
+            edges = list(edge_ring[:3]) if len(edge_ring) >= 3 else [edge, torch.empty_like(edge), torch.empty_like(edge)]
             lp, ep = [t.data_ptr() + W for t in lumas], [t.data_ptr() for t in edges]
 
             def step_sobel(k, ev):
@@ -866,8 +878,12 @@ def main() -> int:
         dom = max(first_kernels, key=first_kernels.get)
         a = kern_table[dom]["GB/s"]
         traffic, traffic_src, traffic_cross = measured_traffic(dom, px_rank, kern_table[dom]["ms"], kern_table[dom].get("device_kernel", ""))
+        if traffic_src:
+            traffic_src += " (FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests, Infinity-Cache hits included -- not DRAM bytes alone; the region "
+            traffic_src += f"re-reads one 805 MB frame and writes {n_ring} edge plane(s) in rotation, all with nontemporal accesses)"
         roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_cross_check": traffic_cross,
+                    "output_planes_in_rotation": n_ring if dom == "gray_sobel_fused_rgb8" else 1,
                     "algo_bytes_per_launch": kern_table[dom]["algo_bytes"], "avg_launch_ms": kern_table[dom]["ms"],
                     "copy_ceiling_GBs": round(copy_ceiling, 1) if copy_ceiling else None,
                     "frac_of_copy_ceiling": round(a / copy_ceiling, 4) if copy_ceiling else None}
