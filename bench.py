@@ -1233,6 +1233,26 @@ def main() -> int:
         forms["pipelined"] = guarded("pipelined", 120, form_body(pipelined_impl, args.steps, "pipelined", True))
         if native is not None:
             halo_timeouts = native.halo_timeouts()
+        # what the communicator of every rank decided and saw: the form its single-frame steps take now (the halo-flag form reviews itself and
+        # goes back to the serial form where the exchange does not run beside the launch), its edge bands' average standstill, an exchange alone
+        comm_diag = None
+        if native is not None:
+            def diag_body():
+                w_, us_ = native.halo_wait_stats()
+                mine = torch.tensor([float(native.step_form_in_use()), us_ / max(w_, 1), native.exchange_alone_us(), float(w_)], dtype=torch.float64, device=device)
+                allr = [torch.empty_like(mine) for _ in range(world)]
+                if rehearsal:
+                    allr = [t_.cpu() for t_ in allr]
+                    dist.all_gather(allr, mine.cpu())
+                else:
+                    dist.all_gather(allr, mine)
+                rows_ = [t_.tolist() for t_ in allr]
+                return {"step_form_in_use": [int(r_[0]) for r_ in rows_], "edge_band_standstill_avg_us": [round(r_[1], 1) for r_ in rows_],
+                        "exchange_alone_at_init_us": [round(r_[2], 1) for r_ in rows_], "standstill_reports": [int(r_[3]) for r_ in rows_],
+                        "note": "form 2 = halo flag, 1 = serial; a rank goes to 1 by itself when its edge bands stand still longer than an exchange alone would take"}
+            comm_diag = guarded("communicator diagnostics", 60, diag_body)
+            if isinstance(comm_diag, dict) and "step_form_in_use" in comm_diag:
+                step_form = min(comm_diag["step_form_in_use"]) if len(set(comm_diag["step_form_in_use"])) == 1 else step_form
 
         bpp = 4 if fused else 6
         a = bpp * px_rank / (step_ms_events * 1e-3) / 1e9
@@ -1251,7 +1271,7 @@ def main() -> int:
                     "repeats": {"ms_per_step": [round(v, 4) for v in rep_ms], "min": round(min(rep_ms), 4),
                                 "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4), "max": round(max(rep_ms), 4),
                                 "note": "the K-step bracket of the single-frame form run again back to back; value / ms_per_step are the first entry"},
-                    "per_rank": breakdown, "exchange_fallback": native is None and args.exchange == "native",
+                    "per_rank": breakdown, "communicators": comm_diag, "exchange_fallback": native is None and args.exchange == "native",
                     "exchange_issuer": "libgrayhip (csrc/comm.hip)" if native is not None else "torch.distributed", "halo_flag_timeouts": halo_timeouts,
                     "shard_step_form": ({2: "halo flag (exchange on a side stream beside one launch; edge bands wait for a flag)", 1: "serial (exchange, then one launch)",
                                          0: "events (exchange || interior rows, then edge rows)"}.get(step_form) if native is not None else None),

@@ -215,6 +215,17 @@ GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
  * that step must not be used.  Reads host-mapped memory; costs nothing.  Callers of the sharded steps through this C API call it after
  * their hipStreamSynchronize / gh_stream_sync (the Python runners' result() does). */
 GH_API int gh_comm_check(gh_comm_t comm);
+/* The halo-flag form reviews itself: its edge bands report how long they stood still in front of their halo row, the communicator looks
+ * at the reports every 32 launches and -- unless a form is forced with gh_comm_set_step_form -- goes back to the serial
+ * form once the average exceeds what the serial form pays instead, one exchange with nothing beside it (timed at gh_comm_init; threshold
+ * 1.25 x that + 2 us): the exchange is then not running beside the launch (seen when the runtime puts the caller's stream
+ * and the side stream on hardware queues of one command-processor pipe: 73 us per step instead of 33; serial: 40).
+ * gh_comm_step_form_in_use: the form the next step takes on a frame that allows the halo-flag form (2 or 1).  gh_comm_halo_wait_stats: the
+ * reports themselves -- waits that had to stand still, microseconds in all. */
+GH_API int gh_comm_step_form_in_use(gh_comm_t comm);
+GH_API int gh_comm_halo_wait_stats(gh_comm_t comm, unsigned int *waits, double *microseconds);
+/* one halo exchange with nothing beside it, in microseconds, as timed when the communicator met its neighbours (gh_comm_init) */
+GH_API double gh_comm_exchange_alone_us(gh_comm_t comm);
 /* Bound of the halo-flag form's device-side waits on this communicator in milliseconds (default: GH_HALO_WAIT_MS, else 10000); -1 = default */
 GH_API int gh_comm_set_halo_wait_ms(gh_comm_t comm, int ms);
 /* One step of a shard: buf holds rows+2 rows (row 0 / rows+1 = halo, rows 1..rows = the shard).  Default (GH_SHARD_STEP_FORM=2, shards

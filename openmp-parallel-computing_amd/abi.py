@@ -74,6 +74,9 @@ SIGNATURES = {
     "gh_comm_halo_timeouts": (C.c_uint, [C.c_void_p]),
     "gh_comm_set_step_form": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_comm_check": (C.c_int, [C.c_void_p]),
+    "gh_comm_step_form_in_use": (C.c_int, [C.c_void_p]),
+    "gh_comm_exchange_alone_us": (C.c_double, [C.c_void_p]),
+    "gh_comm_halo_wait_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "gh_comm_set_halo_wait_ms": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_sharded_conv3x3_step_dev": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int32, _stream]),
     "gh_sharded_pipeline_gray_sobel_dev": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _stream]),

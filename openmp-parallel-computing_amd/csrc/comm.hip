@@ -22,7 +22,7 @@ namespace {
 
 // the slice of the RCCL API used here (rccl.h: ncclGetUniqueId / ncclCommInitRank / ncclSend / ncclRecv / ...)
 constexpr int kIdBytes = 128;
-constexpr size_t kFlagBytes = 512;       // flag (dword 0), trace stamps (bytes 64..127), started (dword 32), warm-up rows (bytes 256..511)
+constexpr size_t kFlagBytes = 512;       // flag (dword 0), trace stamps (bytes 64..127), started (dword 32), standstill counters (dwords 40, 41), warm-up rows (bytes 256..511)
 struct NcclId { char internal[kIdBytes]; };
 using nccl_comm_t = void *;
 enum { kNcclUint8 = 1, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
@@ -122,6 +122,12 @@ struct Comm {
     uint32_t stream_xepoch = 0;
     int step_form = -1;                  // gh_comm_set_step_form: -1 = GH_SHARD_STEP_FORM / the default
     int halo_wait_ms = -1;               // gh_comm_set_halo_wait_ms: -1 = GH_HALO_WAIT_MS / the default (10 s)
+    // review of the halo-flag form (halo_flag_review): what the edge bands have reported up to the last look, and the verdict
+    uint32_t seen_ticks = 0, seen_waits = 0, review_epoch = 0;
+    bool reviewed = false;
+    float exchange_alone_us = 11.f;      // one halo exchange with nothing beside it, timed at gh_comm_init / gh_comm_set_loopback (what the serial form pays per step)
+    bool auto_serial = false;            // the exchange was found NOT to run beside the launch: steps whose form is not forced take the serial form
+    uint32_t last_avg_wait_ticks = 0;
 };
 
 // The stream-of-frames step remembers which buffer's halo rows the previous call sent on their way (stream_buf / stream_xepoch).  Anything
@@ -140,10 +146,16 @@ void neighbours(const Comm *c, int &up, int &down)
     else if (c->loopback == 3) { up = c->rank; down = -1; }      // bottom shard: the mirror image
 }
 
-__global__ void k_set_halo_flag(uint32_t *flag, uint32_t epoch)
+// behind the exchange on the side stream: the flag the edge bands poll -- and, on the way, what the edge bands of EARLIER launches reported
+// about their waits (gh_halo_wait: device counters at flag + 40 / + 41) goes to the host-mapped words the review reads (plain stores)
+__global__ void k_set_halo_flag(uint32_t *flag, uint32_t epoch, uint32_t *host_words)
 {
     GH_HALO_TRACE_AT(flag, 2);
-    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        host_words[2] = __hip_atomic_load(flag + 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        host_words[4] = __hip_atomic_load(flag + 41, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ void k_store_u32(uint32_t *p, uint32_t v)
@@ -167,6 +179,53 @@ __global__ void k_wait_started(const uint32_t *started, uint32_t epoch, unsigned
 }
 
 }  // namespace
+
+// GH_SHARD_STEP_FORM in the environment forces a form like gh_comm_set_step_form does (-1: not set)
+static int env_step_form()
+{
+    static const int v = [] {
+        const char *e = getenv("GH_SHARD_STEP_FORM");
+        if (!e || !*e) return -1;
+        const int f = atoi(e);
+        return (f == 1 || f == 2 || (GH_LAB && f == 0)) ? f : -1;
+    }();
+    return v;
+}
+// the form of the next step where the frame allows the halo-flag form: forced (API, then environment), else 2 until the review says 1
+static int step_form_of(const Comm *c)
+{
+    if (c->step_form >= 0) return c->step_form;
+    if (env_step_form() >= 0) return env_step_form();
+    return c->auto_serial ? 1 : 2;
+}
+static bool form_is_forced(const Comm *c) { return c->step_form >= 0 || env_step_form() >= 0; }
+
+// One row to and from each neighbour, nothing beside it: the warm-up of the peer connections and -- timed over a few repetitions -- what the
+// serial form of a step pays on top of its kernel.  Collective (every rank of the communicator is in gh_comm_init at the same time).
+static int time_exchange_alone(Comm *c, int up, int down)
+{
+    uint8_t *w = reinterpret_cast<uint8_t *>(c->flag_dev) + 256;
+    if (int rc = gh_halo_exchange_dev(c, up, w, w + 64, down, w + 128, w + 192, 64, c->side)) return rc;       // connects the peers
+    GH_HIP_TRY(hipStreamSynchronize(c->side));
+    hipEvent_t a = nullptr, b = nullptr;
+    GH_HIP_TRY(hipEventCreate(&a));
+    GH_HIP_TRY(hipEventCreate(&b));
+    constexpr int kReps = 8;
+    int rc = GH_OK;
+    hipError_t e = hipEventRecord(a, c->side);
+    for (int i = 0; i < kReps && rc == GH_OK && e == hipSuccess; ++i) rc = gh_halo_exchange_dev(c, up, w, w + 64, down, w + 128, w + 192, 64, c->side);
+    if (rc == GH_OK && e == hipSuccess) e = hipEventRecord(b, c->side);
+    if (rc == GH_OK && e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (rc == GH_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (rc != GH_OK) return rc;
+    if (e != hipSuccess) return gh_set_error(GH_ERR_HIP, "timing the halo exchange failed: %s", hipGetErrorString(e));
+    c->exchange_alone_us = ms * 1e3f / kReps;
+    c->exchanges = 0;
+    return GH_OK;
+}
 
 extern "C" {
 
@@ -226,13 +285,8 @@ int gh_comm_init(const uint8_t id[GH_COMM_ID_BYTES], int rank, int world, gh_com
         // can take seconds and block the host.  The halo-flag form queues a wait for `started` on the side stream BEFORE its exchange and bounds
         // every device-side wait (GH_HALO_WAIT_MS), so a first exchange that connected under such a wait could be taken for a lost one.  One
         // 64-byte row to and from each neighbour here (gh_comm_init is collective: every rank is in this call), then the connections exist.
-        if (world > 1) {
-            uint8_t *w = reinterpret_cast<uint8_t *>(c->flag_dev) + 256;
-            const int up = rank > 0 ? rank - 1 : -1, down = rank + 1 < world ? rank + 1 : -1;
-            if (int rc2 = gh_halo_exchange_dev(c, up, w, w + 64, down, w + 128, w + 192, 64, c->side)) return rc2;
-            GH_HIP_TRY(hipStreamSynchronize(c->side));
-            c->exchanges = 0;
-        }
+        if (world > 1)
+            if (int rc2 = time_exchange_alone(c, rank > 0 ? rank - 1 : -1, rank + 1 < world ? rank + 1 : -1)) return rc2;
         return GH_OK;
     }();
     if (rc != GH_OK) {
@@ -253,6 +307,11 @@ int gh_comm_set_loopback(gh_comm_t comm, int mode)
     Comm *c = static_cast<Comm *>(comm);
     c->loopback = mode;
     forget_announced(c);
+    if (mode) {                       // the rehearsal's own figure of an exchange alone (ncclSend / ncclRecv to self)
+        int up, down;
+        neighbours(c, up, down);
+        if (int rc = time_exchange_alone(c, up, down)) return rc;
+    }
     return GH_OK;
 }
 
@@ -266,6 +325,13 @@ int gh_comm_set_step_form(gh_comm_t comm, int form)
     GH_REQUIRE(GH_LAB || form != 0, "form 0 (events) lost its A/B and exists in probe builds only (make probes)");
     Comm *c = static_cast<Comm *>(comm);
     c->step_form = form;
+    c->auto_serial = false;            // (a forced form is the caller's decision; -1 starts the review afresh)
+    c->reviewed = false;
+    c->review_epoch = c->epoch;
+    if (c->timeouts_host) {
+        c->seen_ticks = __atomic_load_n(c->timeouts_host + 2, __ATOMIC_ACQUIRE);
+        c->seen_waits = __atomic_load_n(c->timeouts_host + 4, __ATOMIC_ACQUIRE);
+    }
     forget_announced(c);
     if (c->timeouts_host) __atomic_store_n(c->timeouts_host, 0u, __ATOMIC_RELEASE);      // choosing a form acknowledges waits that gave up earlier
     return GH_OK;
@@ -347,6 +413,30 @@ unsigned int gh_comm_halo_timeouts(gh_comm_t comm)
     return c->timeouts_host ? __atomic_load_n(c->timeouts_host, __ATOMIC_ACQUIRE) : 0;
 }
 
+// Form the next single-frame step of this communicator would take where the frame allows the halo-flag form: 2 or 1 (0 in probe builds) --
+// the forced form, else GH_SHARD_STEP_FORM / 2, else 1 once the review found the exchange not overlapping (halo_flag_review).
+int gh_comm_step_form_in_use(gh_comm_t comm)
+{
+    if (!comm) return -1;
+    const Comm *c = static_cast<const Comm *>(comm);
+    return step_form_of(c);
+}
+
+// One halo exchange with nothing beside it, microseconds: timed over eight repetitions when the communicator met its neighbours
+// (gh_comm_init; gh_comm_set_loopback for the rehearsal) -- what the serial form of a step pays on top of its kernel.
+double gh_comm_exchange_alone_us(gh_comm_t comm) { return comm ? (double)static_cast<const Comm *>(comm)->exchange_alone_us : 0.0; }
+
+// What the edge bands of the halo-flag launches have reported so far: how many of their waits had to stand still and for how many
+// microseconds in all (100 MHz clock; the sum wraps after 42 s of standing still).  Diagnostic; reads host-mapped memory.
+int gh_comm_halo_wait_stats(gh_comm_t comm, unsigned int *waits, double *microseconds)
+{
+    GH_REQUIRE(comm, "null communicator");
+    const Comm *c = static_cast<const Comm *>(comm);
+    if (waits) *waits = c->timeouts_host ? __atomic_load_n(c->timeouts_host + 4, __ATOMIC_ACQUIRE) : 0;
+    if (microseconds) *microseconds = c->timeouts_host ? __atomic_load_n(c->timeouts_host + 2, __ATOMIC_ACQUIRE) / 100.0 : 0.0;
+    return GH_OK;
+}
+
 // After the synchronisation that hands a sharded step's results to the host: did every halo-flag wait of the steps so far see its exchange?
 // (The count lives in host-mapped memory: no device call here.)
 int gh_comm_check(gh_comm_t comm)
@@ -401,7 +491,34 @@ static int halo_flag_guard(Comm *c, hipStream_t s)
     if (c->started_sig) GH_HIP_TRY(hipMemset(c->started_sig, 0, 8));
     c->epoch = c->xepoch = 0;
     c->stream_buf = nullptr;
+    c->seen_ticks = c->seen_waits = c->review_epoch = 0;      // (the standstill counters live in flag_dev and were cleared with it)
+    c->reviewed = false;
+    if (c->timeouts_host) { c->timeouts_host[2] = 0; c->timeouts_host[4] = 0; }
     return GH_OK;
+}
+
+// Does the halo-flag form do what it is for?  Its edge bands report how long they stood still in front of their halo row (gh_halo_wait).
+// A few microseconds are normal for a small shard (the exchange beside a bandwidth-bound launch takes about as long as a 2048-row kernel);
+// tens of them mean the exchange is NOT running beside the launch -- seen when the caller's stream and the side stream land on hardware
+// queues of the same command-processor pipe: `started` is then noticed ~30 us late and the flag kernel starts ~40 us behind the RCCL kernel,
+// 73 us per step where the serial form takes 40 and the healthy halo-flag form 33 (NOTES.md R4.4).  Which queues a process's streams get
+// is the runtime's business, so the communicator looks at the reports every 32 launches and, while the caller has not forced a form, goes
+// back to the serial form for good once the average standstill exceeds what the serial form would pay instead: one exchange with nothing
+// beside it (timed at gh_comm_init: 1.25 x that + 2 us; healthy loopback: 4.5 us against 16, the slow mapping 19 us).  gh_comm_step_form_in_use() / gh_comm_halo_wait_stats() say so.
+static void halo_flag_review(Comm *c)
+{
+    if (c->auto_serial || !c->timeouts_host || c->epoch - c->review_epoch < 32) return;
+    const bool first_look = !c->reviewed;                 // the first 32 launches are run-in (RCCL's set-up, cold caches): noted, not judged
+    c->reviewed = true;
+    c->review_epoch = c->epoch;
+    const uint32_t ticks = __atomic_load_n(c->timeouts_host + 2, __ATOMIC_ACQUIRE), waits = __atomic_load_n(c->timeouts_host + 4, __ATOMIC_ACQUIRE);
+    const uint32_t dt = ticks - c->seen_ticks, dn = waits - c->seen_waits;
+    c->seen_ticks = ticks;
+    c->seen_waits = waits;
+    if (first_look || dn < 8) return;                     // (hardly any band had to wait: nothing to judge)
+    c->last_avg_wait_ticks = dt / dn;
+    // the halo-flag form costs a step its edge bands' standstill, the serial form one exchange with nothing beside it (timed at init)
+    if (!form_is_forced(c) && c->last_avg_wait_ticks > (uint32_t)((c->exchange_alone_us * 1.25f + 2.f) * 100.f)) c->auto_serial = true;
 }
 
 // The halo-flag form needs the caller's stream and the side stream on DIFFERENT hardware queues: the side stream's wait for `started` would
@@ -456,7 +573,7 @@ static int halo_flag_exchange(Comm *c, const GhHaloWait &hw, uint8_t *buf, size_
     if (GH_LAB_INT("GH_HALO_MEMOPS", 0) & 1) {
         GH_HIP_TRY(hipStreamWriteValue32(c->side, c->flag_dev, f, 0));
     } else {
-        k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, f);
+        k_set_halo_flag<<<1, 64, 0, c->side>>>(c->flag_dev, f, c->timeouts_dev);
         GH_LAUNCH_CHECK();
     }
     *flag_number = f;
@@ -490,7 +607,8 @@ static int sharded_step(Comm *c, uint8_t *buf, size_t row_bytes, int rows, hipSt
     //    is not hidden: 40.0 / 62.7 / 110.7 (round 2's default).
     //  0 overlapped with events (probe builds only): exchange on the side stream || interior rows, then two one-row launches behind an event --
     //    pays two cross-queue event hand-overs (~20 us each on this runtime) and two extra launches: 58.2 / 66.9 / 116.7.
-    int form = c->step_form >= 0 ? c->step_form : GH_KNOB_INT("GH_SHARD_STEP_FORM", 2);
+    halo_flag_review(c);
+    int form = step_form_of(c);
     if (form == 2) {                               // frames whose kernel form carries no flag wait (narrow, per-pixel, convolution): serial form
         GhHaloWait probe{};
         probe.pad = 1;
@@ -705,7 +823,8 @@ static int sharded_stream_step(Comm *c, uint8_t *cur, uint8_t *next, size_t rb, 
     if (up < 0 && down < 0) return plain();
     GhHaloWait probe{};
     probe.pad = 1;
-    const int form = c->step_form >= 0 ? c->step_form : GH_KNOB_INT("GH_SHARD_STEP_FORM", 2);
+    halo_flag_review(c);
+    const int form = step_form_of(c);
     if (form != 2 || launch_wait(up < 0, down < 0, probe) != GH_OK || !caller_stream_ok(c, s)) return fallback();
     if (gh_comm_halo_timeouts(c))
         return gh_set_error(GH_ERR_HIP, "an earlier sharded step gave up waiting for its halo rows (%u waits timed out): results of that step are invalid",

@@ -53,7 +53,7 @@ void gh_note_kernel(const char *name);
 struct GhHaloWait {
     const uint32_t *flag;
     uint32_t *started;
-    uint32_t *timeouts;
+    uint32_t *timeouts;           // host-mapped dwords: [0] waits that gave up; [2] / [4]: copies of the standstill counters (flag + 40 / + 41)
     uint32_t epoch;               // what the kernel's first workgroup stores into `started`
     uint32_t wait_epoch;          // what `flag` must have reached before an edge band may request its halo row
     uint32_t pad;                 // host side: 1 = "would this frame run a kernel form that carries the wait?" (GH_OK / GH_NO_FLAG_FORM, nothing launched)
@@ -128,13 +128,31 @@ __device__ __forceinline__ void gh_halo_wait(const GhHaloWait &hw)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     GH_HALO_TRACE_AT(hw.flag, 3);
+    bool stood_still = false;
     for (;;) {
         const uint32_t v = __hip_atomic_load(hw.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int32_t)(v - hw.wait_epoch) >= 0) { GH_HALO_TRACE_AT(hw.flag, 4); return; }
+        if ((int32_t)(v - hw.wait_epoch) >= 0) {
+            GH_HALO_TRACE_AT(hw.flag, 4);
+            // A band that had to stand still says for how long (wave 0 of its workgroup): two counters in DEVICE memory behind the flag --
+            // dword 40 the 100 MHz ticks (modulo 2^32: the host looks at differences), dword 41 the number of such waits -- which the
+            // flag kernel of the next exchange copies into host-mapped words (atomics straight into host memory cost the step 15 us).
+            // A few microseconds are the normal case of a small shard; tens of them mean the exchange is not running beside the launch --
+            // the communicator then goes back to the serial form (comm.hip, halo_flag_review).
+            if (stood_still && threadIdx.x == 0) {
+                uint32_t *stats = const_cast<uint32_t *>(hw.flag) + 40;
+                const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+                // (one wait counts for at most 100 us: the first exchange of a communicator takes milliseconds -- RCCL sets its channels up --
+                //  and must not look like fifty slow steps)
+                __hip_atomic_fetch_add(stats, dt > 10000ull ? 10000u : (uint32_t)dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         if (__builtin_amdgcn_s_memrealtime() - t0 > hw.ticks) {
             if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(hw.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
+        stood_still = true;
         __builtin_amdgcn_s_sleep(8);
     }
 }

@@ -935,9 +935,16 @@ int gh_sobel_init_tables(int device)
 {
     uint8_t *base = nullptr;
     GH_HIP_TRY(hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_lum_lut)));
-    k_fill_lum_lut<<<1, 256, 0, nullptr>>>();
-    GH_LAUNCH_CHECK();
-    GH_HIP_TRY(hipDeviceSynchronize());
+    // On a stream of its own, NOT the null stream: a library that is the first to launch on the null stream of a process changes which
+    // hardware queue that stream is given, and with it how the caller's stream and the communicator's side stream share the command
+    // processor's pipes -- measured: the halo-flag step of a 2048-row shard 73 us per step instead of 33 (NOTES.md R4.4).
+    hipStream_t ts = nullptr;
+    GH_HIP_TRY(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+    k_fill_lum_lut<<<1, 256, 0, ts>>>();
+    const hipError_t le = hipGetLastError();
+    const hipError_t se = le == hipSuccess ? hipStreamSynchronize(ts) : le;
+    (void)hipStreamDestroy(ts);
+    if (se != hipSuccess) return gh_set_error(GH_ERR_HIP, "filling the luma table failed: %s", hipGetErrorString(se));
     if (device >= 0 && device < 64) g_lum_lut_addr[device] = base;
     return GH_OK;
 }

@@ -144,6 +144,22 @@ class NativeHaloComm:
         """Bound of the halo-flag form's device-side waits on this communicator (-1: GH_HALO_WAIT_MS / 10 s)."""
         self.abi.check(self.lib.gh_comm_set_halo_wait_ms(self.handle, int(ms)), "gh_comm_set_halo_wait_ms")
 
+    def step_form_in_use(self) -> int:
+        """2 halo flag / 1 serial: what the next single-frame step takes where the frame allows the halo-flag form (the communicator
+        falls back to 1 by itself when its edge bands report that the exchange does not run beside the launch)."""
+        return int(self.lib.gh_comm_step_form_in_use(self.handle))
+
+    def exchange_alone_us(self) -> float:
+        """One halo exchange with nothing beside it, microseconds (timed by gh_comm_init / gh_comm_set_loopback)."""
+        return float(self.lib.gh_comm_exchange_alone_us(self.handle))
+
+    def halo_wait_stats(self):
+        """(waits that had to stand still, microseconds in all) reported by the edge bands of the halo-flag launches so far."""
+        import ctypes as C
+        n, us = C.c_uint(0), C.c_double(0.0)
+        self.abi.check(self.lib.gh_comm_halo_wait_stats(self.handle, C.byref(n), C.byref(us)), "gh_comm_halo_wait_stats")
+        return int(n.value), float(us.value)
+
     def halo_timeouts(self) -> int:
         return int(self.lib.gh_comm_halo_timeouts(self.handle))
 
