@@ -14,7 +14,7 @@ def test_design_md_figures_are_the_generated_ones():
     doc = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, b = doc.index(gen.BEGIN), doc.index(gen.END) + len(gen.END)
     assert doc[a:b] == gen.block(), "DESIGN.md is stale: run python3 tools/design_figures.py --write"
-    assert len(doc.encode()) < 28 * 1024, "DESIGN.md states what is (eight sections, ~24 KB); the notebook goes to NOTES.md"
+    assert len(doc.encode()) < 30 * 1024, "DESIGN.md states what is (eight sections, < 30 KB); the notebook goes to NOTES.md"
 
 
 def test_manifest_names_existing_files():

@@ -26,14 +26,19 @@ src, dst = args[0], args[1]
 set_latest = "--no-latest" not in sys.argv
 os.makedirs(dst, exist_ok=True)
 ALGO = {"k_fused_dma": 4, "k_fused_stream": 4, "k_gray_rgb_to_plane_w": 4, "k_sobel_dma2": 2, "k_sobel_dma": 2, "k_sobel_stream": 2, "k_copy_stream": 2,
-        "k_gray_inplace_rgb_w": 6}
+        "k_gray_inplace_rgb_w": 6, "k_sobel_dma2_luma": 2, "k_gray_of_plane": 2}
 NPIX = 16384 * 16384
 NSIMD = 1024                      # 256 CUs x 4 SIMDs
 
 
 def kname(s):
-    m = re.search(r"(k_\w+)", s)
-    return m.group(1) if m else None
+    m = re.search(r"(k_\w+)(<[^>]*>)?", s)
+    if not m:
+        return None
+    # the plane Sobel with the luma applied on load (pass k of the multi-pass loop) is the same template with LUMA = 1, its last argument
+    if m.group(1) == "k_sobel_dma2" and m.group(2) and m.group(2).replace(" ", "").endswith(",1>"):
+        return "k_sobel_dma2_luma"
+    return m.group(1)
 
 
 def rows_of(pattern):
