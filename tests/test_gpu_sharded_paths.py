@@ -532,3 +532,118 @@ def test_halo_flag_form_reviews_itself(first_on_null_stream):
     if r["forced_halo_flag"] < 0.9 * r["serial"]:         # the healthy case: the halo-flag form stays
         assert r["form_after"] == 2 and r["later"] <= 1.15 * r["forced_halo_flag"] + 2, r
     assert r["later"] <= 1.25 * best + 3, r               # left to itself: within a quarter of the better form
+
+
+# ---- advisor findings of round 3: the stream step's memory, and callers on the side stream's priority --------------------------------
+
+@pytest.mark.parametrize("lb", LOOPBACK_MODES)
+def test_stream_step_forgets_its_announcement_when_other_calls_touch_the_halo_rows(pkg, oracle, native_comm, torch_mod, lb):
+    """The stream step remembers which buffer's halo rows the previous call sent on their way.  A single-frame step, a bare exchange, a
+    change of form or of the loopback kind in between makes that memory stale: the buffer announced as `next` is then REWRITTEN (rows and
+    poisoned halo rows) before the stream resumes on it -- the resumed step must exchange again instead of waiting for an epoch that has
+    long passed and filtering with whatever the halo rows hold."""
+    t = torch_mod
+    w, h = 2064, 40
+    native_comm.set_loopback(lb)
+    try:
+        frames = [oracle.frame_rand(w, h, 3, seed=70 + i) for i in range(3)]
+        bufs = []
+        for img in frames:
+            b = t.full((h + 2, w, 3), 0x21, dtype=t.uint8, device="cuda")
+            b[1:h + 1] = dev(t, img)
+            bufs.append(b)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        expected = lambda img: loopback_sobel(oracle, oracle.gray_to_plane(img, 0), lb)
+        for breaker in ("single_frame_step", "bare_exchange", "set_step_form", "set_loopback"):
+            step = native_comm.bind_fused_stream_step(bufs, edge, h, 0)
+            step(0)                                   # filters bufs[0], announces bufs[1]: its halo rows are on their way
+            t.cuda.synchronize()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[0])), breaker
+            # something else happens on the communicator, then bufs[1] gets a NEW frame and poisoned halo rows
+            if breaker == "single_frame_step":
+                native_comm.bind_fused_step(bufs[2], t.empty_like(edge), h, 0)()
+            elif breaker == "bare_exchange":
+                up, down = (0 if lb in (1, 3) else -1), (0 if lb in (1, 2) else -1)
+                native_comm.halo_exchange(up, bufs[2][1], bufs[2][0], down, bufs[2][h], bufs[2][h + 1], w * 3, t.cuda.current_stream().cuda_stream)
+            elif breaker == "set_step_form":
+                native_comm.set_step_form(2)
+                native_comm.set_step_form(-1)
+            else:
+                native_comm.set_loopback(lb)
+            frames[1] = oracle.frame_rand(w, h, 3, seed=170 + len(breaker))
+            bufs[1][1:h + 1] = dev(t, frames[1])
+            bufs[1][0] = 0x6B
+            bufs[1][h + 1] = 0x6B
+            n0 = native_comm.exchange_count()
+            step(1)                                   # the announcement is void: bufs[1] is exchanged beside this launch
+            t.cuda.synchronize()
+            native_comm.check()
+            assert np.array_equal(edge.cpu().numpy(), expected(frames[1])), breaker
+            assert native_comm.exchange_count() - n0 == 2, breaker          # bufs[1] again + the announcement of bufs[2]
+    finally:
+        native_comm.set_loopback(0)
+
+
+def test_caller_on_the_side_streams_priority_takes_the_serial_form(pkg, oracle, native_comm, torch_mod):
+    """The halo-flag form needs the caller's stream and the side stream on different hardware queues; a caller's stream of the greatest
+    priority (the side stream's own) may share its queue -- the wait for `started` would sit in front of the launch that stores it.  Such
+    steps take the serial form: right pixels, one exchange per step, no wait gives up; on a normal-priority stream the form stays."""
+    t = torch_mod
+    w, h = 4096, 64
+    img = oracle.frame_rand(w, h, 3, seed=404)
+    want = loopback_sobel(oracle, oracle.gray_to_plane(img, 0), 1)
+    native_comm.set_loopback(1)
+    try:
+        buf = t.full((h + 2, w, 3), 0x2C, dtype=t.uint8, device="cuda")
+        buf[1:h + 1] = dev(t, img)
+        edge = t.zeros((h, w), dtype=t.uint8, device="cuda")
+        step = native_comm.bind_fused_step(buf, edge, h, 0)
+        for prio in (-1, 0):                          # torch: -1 = high priority
+            s = t.cuda.Stream(priority=prio)
+            s.wait_stream(t.cuda.current_stream())
+            with t.cuda.stream(s):
+                edge.zero_()
+                buf[0] = 0x2C
+                buf[h + 1] = 0x2C
+                n0 = native_comm.exchange_count()
+                for _ in range(3):
+                    step()
+            s.synchronize()
+            native_comm.check()
+            assert native_comm.exchange_count() - n0 == 3
+            assert np.array_equal(edge.cpu().numpy(), want), prio
+            t.cuda.current_stream().wait_stream(s)
+    finally:
+        native_comm.set_loopback(0)
+
+
+def test_runner_result_checks_the_communicator(pkg, oracle, torch_mod):
+    """ShardedFusedGraySobel.result(): the synchronisation that hands the edge plane to the host is followed by gh_comm_check -- a step
+    whose halo wait gave up (bound 0 ms here) raises instead of returning pixels computed from stale halo rows."""
+    t = torch_mod
+    w, h = 16384, 2048
+    comm = pkg.sharding.NativeHaloComm(0, 1)
+    try:
+        comm.set_loopback(1)
+        runner = pkg.sharding.ShardedFusedGraySobel(pkg.sharding.ShardGeometry(0, 1, w, 0, h), pkg.sharding.HipBackend(0), "cuda")
+        # (a world of one binds no communicator by itself: the rehearsal wires the loopback communicator in by hand)
+        runner._native = comm.bind_fused_step(runner.rgb, runner.edge, h, 0)
+        runner._native_comm = comm
+        runner.shard.copy_(dev(t, oracle.frame_rand(w, h, 3, seed=8)))
+        runner.step()
+        good = runner.result().clone()
+        comm.set_halo_wait_ms(0)
+        runner.rgb[0] = 0x01
+        runner.rgb[h + 1] = 0x02
+        runner.step()
+        t.cuda.synchronize()
+        comm.set_halo_wait_ms(-1)
+        if comm.halo_timeouts() == 0:
+            pytest.skip("the exchange landed before the edge bands asked for their halo row on this box")
+        with pytest.raises(pkg.GrayHipError):
+            runner.result()
+        comm.set_step_form(-1)                          # acknowledged: the next step is clean again
+        runner.step()
+        assert t.equal(runner.result(), good)
+    finally:
+        comm.close()
