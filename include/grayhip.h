@@ -232,13 +232,17 @@ GH_API int gh_comm_set_halo_wait_ms(gh_comm_t comm, int ms);
  * that run an LDS-DMA ring kernel: 1024 columns and more): the one-row exchange runs on the communicator's side stream BESIDE one launch
  * over the whole shard on `stream`; only the workgroups of the first / last band wait -- inside the kernel -- for a flag set behind the
  * ncclRecv, so the step costs max(kernel, exchange + one band) and the caller's stream sees one launch and no event.  Other shards, and
- * GH_SHARD_STEP_FORM=1: the exchange on `stream`, then one launch (serial).  GH_SHARD_STEP_FORM=0: exchange on the side stream || interior
- * rows, then the first and last row behind an event (two event hand-overs and two extra launches: the slowest form measured, comm.hip).
+ * GH_SHARD_STEP_FORM=1: the exchange on `stream`, then one launch (serial).  (Probe builds keep form 0: exchange on the side stream ||
+ * interior rows, then the first and last row behind an event -- two event hand-overs and two extra launches, the slowest form measured.)
+ * `stream` should be a normal-priority stream: a caller's stream of the greatest priority may share the side stream's hardware queue, and
+ * the step then takes the serial form by itself.  All device-side waits are bounded (gh_comm_set_halo_wait_ms); call gh_comm_check after
+ * the synchronisation that hands the output to the host.
  * Neighbours are rank-1 (above) and rank+1 (below); rank 0 / world-1 own the frame border.
  *   fused: buf = interleaved RGB8/RGBA8 rows, the halo is one RGB row (the luma plane never exists in HBM)
  *   sobel: buf = luma rows (written by gh_gray_rgb8_to_plane_dev into rows 1..rows), the halo is one luma row */
-/* form: 2 halo flag, 1 serial, 0 events, -1 = GH_SHARD_STEP_FORM or the default (2).  The forms differ only in how a rank orders its own
- * exchange and kernel; ranks of one job may use different forms. */
+/* form: 2 halo flag, 1 serial (0 events: probe builds only), -1 = GH_SHARD_STEP_FORM, else the self-reviewing default (2 until the edge
+ * bands report that the exchange does not run beside the launch, then 1).  The forms differ only in how a rank orders its own exchange and
+ * kernel; ranks of one job may use different forms.  Forcing a form also acknowledges waits that gave up earlier. */
 GH_API int gh_comm_set_step_form(gh_comm_t comm, int form);
 GH_API int gh_sharded_fused_step_dev(gh_comm_t comm, uint8_t *rgb_buf, uint8_t *edge, int width, int rows, int channels,
                                      int mode, gh_stream_t stream);

@@ -169,7 +169,8 @@ class NativeHaloComm:
         self.abi.check(self.lib.gh_comm_check(self.handle), "gh_comm_check")
 
     def set_step_form(self, form: int):
-        """Form of the single-frame sharded steps: 2 halo flag (default), 1 serial, 0 events, -1 = environment / default."""
+        """Form of the single-frame sharded steps: 2 halo flag, 1 serial (0 events: probe build only), -1 = environment, else the
+        self-reviewing default (2 until the edge bands report that the exchange does not run beside the launch, then 1)."""
         self.abi.check(self.lib.gh_comm_set_step_form(self.handle, int(form)), "gh_comm_set_step_form")
 
     def close(self):
