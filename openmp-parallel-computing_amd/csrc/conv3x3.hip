@@ -371,7 +371,7 @@ extern "C" int gh_conv3x3_rgb8_rows_dev(const uint8_t *src, uint8_t *dst, int wi
         t.inv = 1.0f / n;
         t.half_inv = 0.5f / n;
     }
-    // LDS-DMA ring kernel: any row of 1024 bytes and more, any alignment (GH_CONV_DMA=0: the register-staged strips, aligned frames only)
+    // LDS-DMA ring kernel: any row of 1024 bytes and more, any alignment (probe builds, GH_CONV_DMA=0: the register-staged strips, aligned frames only)
     if (exact && wb >= stream_core::STRIP_PX && wb < (1ll << 31) && GH_LAB_INT("GH_CONV_DMA", 1)) {
         const int span = stream_core::STRIP_PX * stream_core::WAVES_PER_BLOCK;
         const int groups_x = (int)((wb + span - 1) / span);

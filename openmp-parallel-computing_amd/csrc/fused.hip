@@ -9,10 +9,10 @@
 //   k_fused_dma         default for RGB8 / RGBA8, width >= 1024: strip streaming (stream_core.h) with an LDS row ring filled by
 //                       LDS-DMA (global_load_lds_dwordx4, three rows deep): a wave's 3 KiB of a row lands lane-linear
 //                       in LDS, every lane reads back its 16 consecutive pixels (48 B), converts to luma in f32 and
-//                       feeds the f32 Sobel row step directly (no byte round trip).  GH_FUSED_DMA=0 turns it off.
-//   k_fused_stream      narrow frames (or GH_FUSED_DMA=0): the same strip streaming, rows staged through registers
+//                       feeds the f32 Sobel row step directly (no byte round trip).
+//   k_fused_stream      frames narrower than 1024 columns: the same strip streaming, rows staged through registers
 //                       (coalesced dwordx4 loads -> ds_write -> ds_read de-interleave).
-//   k_gray_sobel_fused  the LDS-tile form (sobel_tile.h); GH_FUSED_IMPL=tile
+//   k_gray_sobel_fused  the LDS-tile form (sobel_tile.h): probe builds only (`make probes`), like every GH_FUSED_* tuning knob
 #include "stream_core.h"
 #ifdef GH_ENABLE_PROBES
 #include "sobel_tile.h"

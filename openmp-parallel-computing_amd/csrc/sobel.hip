@@ -2,14 +2,16 @@
 //
 // Replaces monolithic/src/sobel.c:6-25 (sobel_edge).  Bound: HBM, 1 R + 1 W byte per pixel, no MFMA.
 //
-//   k_sobel_dma    : default fast path (width % 16 == 0, width >= 1024, 16-byte aligned planes): strip streaming -- 3x3
-//                    reuse in registers, halo through DPP (stream_core.h) -- with rows brought HBM -> LDS by LDS-DMA
-//                    (global_load_lds_dwordx4), three rows deep; GH_SOBEL_DMA=0 turns it off
-//   k_sobel_stream : the same strip streaming with register-staged loads: narrow frames, GH_SOBEL_DMA=0, and -- with
-//                    unaligned vector accesses -- frames whose width is not a multiple of 16 or whose planes are not
-//                    16-byte aligned (first width & ~15 columns; k_sobel_px_cols takes the remaining columns)
-//   k_sobel_tiled  : the LDS-tile form (tile + one-pixel halo staged in LDS, sobel_tile.h); GH_SOBEL_IMPL=tile
-//   k_sobel_px     : one pixel per lane, any geometry / alignment (small unaligned frames, widths < 16)
+//   k_sobel_dma2   : large aligned frames whose width is a multiple of 8192: two neighbouring 1 KiB strips per wave, regular bands
+//   k_sobel_dma    : every other frame of 1024 columns and more, any alignment: strip streaming -- 3x3 reuse in registers, halo
+//                    through DPP (stream_core.h) -- with rows brought HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), three rows deep
+//   k_sobel_stream : the same strip streaming with register-staged loads: frames narrower than 1024 columns (first width & ~15
+//                    columns; k_sobel_px takes the remaining columns)
+//   k_sobel_px     : one pixel per lane, any geometry / alignment (small unaligned frames, widths < 16, column tails)
+//   every one of them also with LUMA = 1: lum(e, e, e) applied on load -- pass k >= 2 of the reference's gray + Sobel loop
+//   (gh_sobel_of_gray_u8_dev; stream_core::plane_row_pairs)
+// Probe builds only (-DGH_ENABLE_PROBES, `make probes`): k_sobel_dma4, k_sobel_tiled (the LDS-tile form, sobel_tile.h), other ring depths
+// and store policies, the access-pattern probes, and the GH_SOBEL_* knobs that select them.
 #include "stream_core.h"
 #ifdef GH_ENABLE_PROBES
 #include "sobel_tile.h"
