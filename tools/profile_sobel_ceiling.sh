@@ -10,14 +10,14 @@ WANT=${*:-timing stats ea_rd ea_wr tcc tcp ta1 ta2 tlb sq lds}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 has() { [[ " $WANT " == *" $1 "* ]]; }
-if has timing; then timeout -k 10 200 python3 tools/sobel_ceiling.py --rounds 3 > "$OUT/timing.txt" 2> "$OUT/timing.err"; echo "timing rc $?"; fi
+if has timing; then timeout -k 10 200 python3 ${GH_CEILING_TOOL:-tools/sobel_ceiling.py} --rounds 3 > "$OUT/timing.txt" 2> "$OUT/timing.err"; echo "timing rc $?"; fi
 if has stats; then
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 tools/sobel_ceiling.py --launches 100 > "$OUT/stats.txt" 2> "$OUT/stats.err"; echo "stats rc $?"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 ${GH_CEILING_TOOL:-tools/sobel_ceiling.py} --launches 100 > "$OUT/stats.txt" 2> "$OUT/stats.err"; echo "stats rc $?"
 fi
 pass() {   # name, counters...
   local name=$1; shift
   has "$name" || return 0
-  timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 tools/sobel_ceiling.py --launches 40 > "$OUT/pmc_$name.txt" 2> "$OUT/pmc_$name.err"
+  timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 ${GH_CEILING_TOOL:-tools/sobel_ceiling.py} --launches 40 > "$OUT/pmc_$name.txt" 2> "$OUT/pmc_$name.err"
   echo "pmc $name rc $?"
 }
 pass ea_rd   TCC_EA0_RDREQ TCC_EA0_RDREQ_LEVEL TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_TAG_STALL
