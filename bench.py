@@ -1239,7 +1239,8 @@ def main() -> int:
         if native is not None:
             def diag_body():
                 w_, us_ = native.halo_wait_stats()
-                mine = torch.tensor([float(native.step_form_in_use()), us_ / max(w_, 1), native.exchange_alone_us(), float(w_)], dtype=torch.float64, device=device)
+                mine = torch.tensor([float(native.step_form_in_use()), us_ / max(w_, 1), native.exchange_alone_us(), float(w_), float(native.side_stream_replacements())],
+                                    dtype=torch.float64, device=device)
                 allr = [torch.empty_like(mine) for _ in range(world)]
                 if rehearsal:
                     allr = [t_.cpu() for t_ in allr]
@@ -1249,7 +1250,9 @@ def main() -> int:
                 rows_ = [t_.tolist() for t_ in allr]
                 return {"step_form_in_use": [int(r_[0]) for r_ in rows_], "edge_band_standstill_avg_us": [round(r_[1], 1) for r_ in rows_],
                         "exchange_alone_at_init_us": [round(r_[2], 1) for r_ in rows_], "standstill_reports": [int(r_[3]) for r_ in rows_],
-                        "note": "form 2 = halo flag, 1 = serial; a rank goes to 1 by itself when its edge bands stand still longer than an exchange alone would take"}
+                        "side_stream_replacements": [int(r_[4]) for r_ in rows_],
+                        "note": "form 2 = halo flag, 1 = serial; when its edge bands stand still longer than an exchange alone would take a rank swaps its side stream (another hardware "
+                                "queue) up to twice, then goes to form 1 by itself"}
             comm_diag = guarded("communicator diagnostics", 60, diag_body)
             if isinstance(comm_diag, dict) and "step_form_in_use" in comm_diag:
                 step_form = min(comm_diag["step_form_in_use"]) if len(set(comm_diag["step_form_in_use"])) == 1 else step_form

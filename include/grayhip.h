@@ -216,13 +216,16 @@ GH_API unsigned int gh_comm_halo_timeouts(gh_comm_t comm);
  * their hipStreamSynchronize / gh_stream_sync (the Python runners' result() does). */
 GH_API int gh_comm_check(gh_comm_t comm);
 /* The halo-flag form reviews itself: its edge bands report how long they stood still in front of their halo row, the communicator looks
- * at the reports every 32 launches and -- unless a form is forced with gh_comm_set_step_form -- goes back to the serial
- * form once the average exceeds what the serial form pays instead, one exchange with nothing beside it (timed at gh_comm_init; threshold
- * 1.25 x that + 2 us): the exchange is then not running beside the launch (seen when the runtime puts the caller's stream
+ * at the reports every 32 launches; once the average exceeds what the serial form pays instead -- one exchange with nothing beside
+ * it, timed at gh_comm_init; threshold 1.25 x that + 2 us -- it swaps the side stream for a fresh one (another hardware queue; up to twice) and
+ * then, unless a form is forced with gh_comm_set_step_form, goes back to the serial form: the exchange is then not running beside the launch (seen when the runtime puts the caller's stream
  * and the side stream on hardware queues of one command-processor pipe: 73 us per step instead of 33; serial: 40).
  * gh_comm_step_form_in_use: the form the next step takes on a frame that allows the halo-flag form (2 or 1).  gh_comm_halo_wait_stats: the
  * reports themselves -- waits that had to stand still, microseconds in all. */
 GH_API int gh_comm_step_form_in_use(gh_comm_t comm);
+/* how many times the review has swapped the side stream for a fresh one (another hardware queue) before judging again: 0 in a healthy
+ * process, at most 2 -- after that the serial form */
+GH_API int gh_comm_side_stream_replacements(gh_comm_t comm);
 GH_API int gh_comm_halo_wait_stats(gh_comm_t comm, unsigned int *waits, double *microseconds);
 /* one halo exchange with nothing beside it, in microseconds, as timed when the communicator met its neighbours (gh_comm_init) */
 GH_API double gh_comm_exchange_alone_us(gh_comm_t comm);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gh_comm_set_step_form": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_comm_check": (C.c_int, [C.c_void_p]),
     "gh_comm_step_form_in_use": (C.c_int, [C.c_void_p]),
+    "gh_comm_side_stream_replacements": (C.c_int, [C.c_void_p]),
     "gh_comm_exchange_alone_us": (C.c_double, [C.c_void_p]),
     "gh_comm_halo_wait_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "gh_comm_set_halo_wait_ms": (C.c_int, [C.c_void_p, C.c_int]),

@@ -125,6 +125,8 @@ struct Comm {
     // review of the halo-flag form (halo_flag_review): what the edge bands have reported up to the last look, and the verdict
     uint32_t seen_ticks = 0, seen_waits = 0, review_epoch = 0;
     bool reviewed = false;
+    int side_replacements = 0;           // side streams given up because the exchange did not run beside the launch on them
+    hipStream_t retired_side[2] = {};
     float exchange_alone_us = 11.f;      // one halo exchange with nothing beside it, timed at gh_comm_init / gh_comm_set_loopback (what the serial form pays per step)
     bool auto_serial = false;            // the exchange was found NOT to run beside the launch: steps whose form is not forced take the serial form
     uint32_t last_avg_wait_ticks = 0;
@@ -357,6 +359,8 @@ int gh_comm_destroy(gh_comm_t comm)
     for (int i = 0; i < Comm::kPrefetch; ++i)
         if (c->pf_landed[i]) (void)hipEventDestroy(c->pf_landed[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
+    for (hipStream_t rs : c->retired_side)
+        if (rs) { (void)hipStreamSynchronize(rs); (void)hipStreamDestroy(rs); }
     if (c->flag_dev) (void)hipFree(c->flag_dev);
     if (c->started_sig) (void)hipFree(c->started_sig);
     if (c->timeouts_host) (void)hipHostFree(c->timeouts_host);
@@ -421,6 +425,9 @@ int gh_comm_step_form_in_use(gh_comm_t comm)
     const Comm *c = static_cast<const Comm *>(comm);
     return step_form_of(c);
 }
+
+// side streams the review has replaced so far (0 in a healthy process; at most 2, then the serial form)
+int gh_comm_side_stream_replacements(gh_comm_t comm) { return comm ? static_cast<const Comm *>(comm)->side_replacements : 0; }
 
 // One halo exchange with nothing beside it, microseconds: timed over eight repetitions when the communicator met its neighbours
 // (gh_comm_init; gh_comm_set_loopback for the rehearsal) -- what the serial form of a step pays on top of its kernel.
@@ -502,9 +509,10 @@ static int halo_flag_guard(Comm *c, hipStream_t s)
 // tens of them mean the exchange is NOT running beside the launch -- seen when the caller's stream and the side stream land on hardware
 // queues of the same command-processor pipe: `started` is then noticed ~30 us late and the flag kernel starts ~40 us behind the RCCL kernel,
 // 73 us per step where the serial form takes 40 and the healthy halo-flag form 33 (NOTES.md R4.4).  Which queues a process's streams get
-// is the runtime's business, so the communicator looks at the reports every 32 launches and, while the caller has not forced a form, goes
-// back to the serial form for good once the average standstill exceeds what the serial form would pay instead: one exchange with nothing
-// beside it (timed at gh_comm_init: 1.25 x that + 2 us; healthy loopback: 4.5 us against 16, the slow mapping 19 us).  gh_comm_step_form_in_use() / gh_comm_halo_wait_stats() say so.
+// is the runtime's business, so the communicator looks at the reports every 32 launches; once the average standstill exceeds what the serial
+// form would pay instead -- one exchange with nothing beside it, timed at gh_comm_init: 1.25 x that + 2 us (healthy loopback: 4.5 us against
+// 16, the slow mapping 19-45 us) -- it first swaps the side stream for a fresh one, which gets another hardware queue (measured: 32 us per
+// step again after ONE swap), and after two swaps that did not help goes back to the serial form for good unless the caller forced a form.  gh_comm_step_form_in_use() / gh_comm_halo_wait_stats() say so.
 static void halo_flag_review(Comm *c)
 {
     if (c->auto_serial || !c->timeouts_host || c->epoch - c->review_epoch < 32) return;
@@ -518,7 +526,20 @@ static void halo_flag_review(Comm *c)
     if (first_look || dn < 8) return;                     // (hardly any band had to wait: nothing to judge)
     c->last_avg_wait_ticks = dt / dn;
     // the halo-flag form costs a step its edge bands' standstill, the serial form one exchange with nothing beside it (timed at init)
-    if (!form_is_forced(c) && c->last_avg_wait_ticks > (uint32_t)((c->exchange_alone_us * 1.25f + 2.f) * 100.f)) c->auto_serial = true;
+    if (c->last_avg_wait_ticks <= (uint32_t)((c->exchange_alone_us * 1.25f + 2.f) * 100.f)) return;
+    // Before giving the form up: ANOTHER side stream.  The trouble is the hardware queue the side stream was given (it shares a pipe with the
+    // caller's); a second high-priority stream gets another queue.  Up to two replacements, each judged by the next windows; then serial.
+    if (c->side_replacements < 2) {
+        hipStream_t fresh = nullptr;
+        if (hipStreamSynchronize(c->side) == hipSuccess && hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, c->side_prio) == hipSuccess) {
+            c->retired_side[c->side_replacements++] = c->side;      // (destroyed with the communicator: RCCL may still hold per-stream state)
+            c->side = fresh;
+            c->reviewed = false;                                      // the new stream's first window is run-in again (RCCL sets it up: milliseconds)
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    if (!form_is_forced(c)) c->auto_serial = true;
 }
 
 // The halo-flag form needs the caller's stream and the side stream on DIFFERENT hardware queues: the side stream's wait for `started` would

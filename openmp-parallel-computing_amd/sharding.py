@@ -149,6 +149,10 @@ class NativeHaloComm:
         falls back to 1 by itself when its edge bands report that the exchange does not run beside the launch)."""
         return int(self.lib.gh_comm_step_form_in_use(self.handle))
 
+    def side_stream_replacements(self) -> int:
+        """Side streams the halo-flag review has swapped for a fresh one (0 in a healthy process, at most 2)."""
+        return int(self.lib.gh_comm_side_stream_replacements(self.handle))
+
     def exchange_alone_us(self) -> float:
         """One halo exchange with nothing beside it, microseconds (timed by gh_comm_init / gh_comm_set_loopback)."""
         return float(self.lib.gh_comm_exchange_alone_us(self.handle))
