@@ -24,6 +24,7 @@ contract's bracket (barrier + synchronize on both sides, MAX over ranks):
                   its edge rows with its neighbours and filters its shard.  libgrayhip's default form runs the exchange on a side
                   stream beside ONE launch over the shard whose first / last band wait, inside the kernel, for a flag set behind
                   the ncclRecv (csrc/comm.hip; GH_SHARD_STEP_FORM=1: exchange, then launch);
+    single_frame_serial_form  the same step with the serial form forced (exchange, then launch): what the halo-flag form has to beat;
     end_to_end    single_frame preceded by the H2D copy of the rank's shard from pinned host memory (SURVEY 8(d));
     stream_of_frames  the single-frame step on a ring of eight DIFFERENT frames (no frame seen twice in a row: nothing cached);
     pipelined     a different experiment, reported beside them: the same stream, the halo rows of frame k+1 travelling beside the
@@ -1210,6 +1211,17 @@ def main() -> int:
                     native.check()                                  # (behind run_form's final synchronisation)
                 return res
             return body
+
+        # (a') the single-frame step with the SERIAL form forced on every rank (exchange on the caller's stream, then one launch): the comparison
+        # the halo-flag form has to win -- over xGMI an exchange alone may cost more than the loopback's 8-11 us, and this line then says by how much
+        if native is not None:
+            def serial_body():
+                native.set_step_form(1)
+                try:
+                    return form_body(single_impl, args.steps, "single_frame_serial_form", True)()
+                finally:
+                    native.set_step_form(-1)
+            forms["single_frame_serial_form"] = guarded("single_frame_serial_form", 120, serial_body)
 
         # (b) end to end: the shard comes from pinned host memory first (H2D scatter), then the single-frame step
         def e2e_body():
